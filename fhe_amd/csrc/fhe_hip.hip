@@ -1,0 +1,802 @@
+// fhe_hip.hip — C-ABI (include/fhe_hip.h) over the gfx950 kernels: context, tables, key store,
+// and the evaluator pipelines (multiply+relinearize+rescale, rotation key switch).
+// Host-side table construction follows BaseConverter::Impl::Impl() (reference src/base_converter.cpp:122-187).
+#include "../../include/fhe_hip.h"
+#include "ntt_kernels.h"
+#include "pointwise_kernels.h"
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+typedef unsigned __int128 u128;
+
+static thread_local std::string g_create_error;
+
+namespace {
+
+struct RotKeyDev {
+  u64 *beta_m = nullptr, *alpha_m = nullptr;  // [(L+K)][N], Montgomery form
+};
+
+struct ProfEntry {
+  std::string name;
+  uint64_t launches = 0;
+  double total_ms = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace
+
+struct fhe_hip_ctx {
+  int device = 0;
+  uint32_t logN = 0, L = 0, K = 0, M = 0, logR = 0;
+  u64 N = 0;
+  bool sp = false;  // every prime = 1 (mod 2^32): multiplication-free Montgomery quotient
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::vector<u64> primes;
+  // device tables
+  PrimeC *d_primes = nullptr;
+  u64 *d_tw_fwd = nullptr, *d_tw_inv = nullptr;  // [M][N]
+  u32 *d_iota = nullptr;                         // [M] identity modulus map
+  u32 *d_rotmap = nullptr;                       // [L+1][M]: row Li: cm < Li ? cm : L + cm - Li
+  u64 *d_hat_pi_inv_m = nullptr;                 // [K]          mod p_k
+  u64 *d_neg_hat_pi_qj_m = nullptr;              // [L][K]       mod q_l
+  u64 *d_Pinv_qj_m = nullptr;                    // [L]          mod q_j
+  u64 *d_hat_qj_inv_m = nullptr;                 // [L-1][L]     mod q_j
+  u64 *d_hat_qj_pi_m = nullptr;                  // [L-1][K][L]  mod p_k
+  u64 *d_qinv_m = nullptr;                       // [M][M]: (P[a]^-1 mod P[j]) Montgomery, row a
+  // keys
+  u64 *d_mk_beta = nullptr, *d_mk_alpha = nullptr;  // [L][L][N] Montgomery form
+  std::map<u64, RotKeyDev> rot_keys;
+  std::map<u64, u32 *> galois_perm;
+  // workspaces (grow-only)
+  void *ws[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t ws_bytes[6] = {0, 0, 0, 0, 0, 0};
+  void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t stage_bytes[4] = {0, 0, 0, 0};
+  // profiling
+  bool prof = false;
+  std::vector<ProfEntry> prof_entries;
+};
+
+namespace {
+
+#define HIPCHK(c, call)                                                                        \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      (c)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+      return FHE_HIP_ERR_HIP;                                                                  \
+    }                                                                                          \
+  } while (0)
+
+#define FAIL(c, code, msg) do { (c)->err = (msg); return (code); } while (0)
+#define TRY(x) do { int rc_ = (x); if (rc_ != FHE_HIP_OK) return rc_; } while (0)
+
+// ---- host modular helpers (table construction only) -------------------------------------------
+u64 h_mulmod(u64 a, u64 b, u64 p) { return (u64)(((u128)a * b) % p); }
+u64 h_powmod(u64 a, u64 e, u64 p) {
+  u64 r = 1; a %= p;
+  while (e) { if (e & 1) r = h_mulmod(r, a, p); a = h_mulmod(a, a, p); e >>= 1; }
+  return r;
+}
+u64 h_invmod(u64 a, u64 p) { return h_powmod(a % p, p - 2, p); }
+u64 h_to_mont(u64 x, u64 p) { return (u64)((((u128)(x % p)) << 64) % p); }
+size_t h_brv(size_t x, uint32_t bits) {
+  size_t r = 0;
+  for (uint32_t i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+  return r;
+}
+// fHE::product_of (include/fHE/yell.hpp:9-21) over P[first..first+n) skipping `skip`, mod P[m]
+u64 h_product_of(const std::vector<u64> &P, uint32_t first, uint32_t n, int skip, uint32_t m) {
+  u64 prod = 1;
+  for (uint32_t i = 0; i < n; ++i) {
+    if ((int)i == skip) continue;
+    prod = h_mulmod(prod, P[first + i] % P[m], P[m]);
+  }
+  return prod;
+}
+
+template <typename T>
+int upload(fhe_hip_ctx *c, T **dst, const std::vector<T> &v) {
+  size_t bytes = (v.size() ? v.size() : 1) * sizeof(T);
+  HIPCHK(c, hipMalloc((void **)dst, bytes));
+  if (!v.empty()) HIPCHK(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return FHE_HIP_OK;
+}
+
+int ensure_ws(fhe_hip_ctx *c, int slot, size_t bytes) {
+  if (c->ws_bytes[slot] >= bytes) return FHE_HIP_OK;
+  if (c->ws[slot]) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->ws[slot])); c->ws[slot] = nullptr; c->ws_bytes[slot] = 0; }
+  HIPCHK(c, hipMalloc(&c->ws[slot], bytes));
+  c->ws_bytes[slot] = bytes;
+  return FHE_HIP_OK;
+}
+int ensure_stage(fhe_hip_ctx *c, int slot, size_t bytes) {
+  if (c->stage_bytes[slot] >= bytes) return FHE_HIP_OK;
+  if (c->stage[slot]) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->stage[slot])); c->stage[slot] = nullptr; c->stage_bytes[slot] = 0; }
+  HIPCHK(c, hipMalloc(&c->stage[slot], bytes));
+  c->stage_bytes[slot] = bytes;
+  return FHE_HIP_OK;
+}
+
+// ---- launch helper with optional per-kernel event timing ---------------------------------------
+ProfEntry *prof_entry(fhe_hip_ctx *c, const char *name) {
+  for (auto &e : c->prof_entries) if (e.name == name) return &e;
+  c->prof_entries.push_back(ProfEntry());
+  c->prof_entries.back().name = name;
+  return &c->prof_entries.back();
+}
+void prof_drain(fhe_hip_ctx *c) {
+  for (auto &e : c->prof_entries) {
+    for (auto &pr : e.pending) {
+      hipEventSynchronize(pr.second);
+      float ms = 0;
+      hipEventElapsedTime(&ms, pr.first, pr.second);
+      e.total_ms += ms; e.launches += 1;
+      hipEventDestroy(pr.first); hipEventDestroy(pr.second);
+    }
+    e.pending.clear();
+  }
+}
+
+#define LAUNCH(c, name, kern, grid, block, ...)                                                  \
+  do {                                                                                           \
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;                                                   \
+    if ((c)->prof) { hipEventCreate(&ev0_); hipEventCreate(&ev1_); hipEventRecord(ev0_, (c)->stream); } \
+    hipLaunchKernelGGL(kern, grid, block, 0, (c)->stream, __VA_ARGS__);                          \
+    if ((c)->prof) { hipEventRecord(ev1_, (c)->stream); prof_entry((c), name)->pending.push_back({ev0_, ev1_}); } \
+    HIPCHK(c, hipGetLastError());                                                                \
+  } while (0)
+
+#define LAUNCH_SP(c, name, kern, grid, block, ...)                                               \
+  do {                                                                                           \
+    if ((c)->sp) LAUNCH(c, name, (kern<true>), grid, block, __VA_ARGS__);                        \
+    else LAUNCH(c, name, (kern<false>), grid, block, __VA_ARGS__);                               \
+  } while (0)
+
+// ---- NTT launchers ------------------------------------------------------------------------------
+struct NttPlan {
+  const u64 *src; u64 *dst;
+  const u32 *midx; u32 mdiv, mper, smod;
+  u32 nl;        // limbs per batch entry
+  u32 batch;
+  u64 src_bstride, dst_bstride;
+};
+
+template <bool SP, bool INV>
+int launch_cols(fhe_hip_ctx *c, const NttArgs &a, u32 nl, u32 batch) {
+  const char *name = INV ? "ntt_inv_cols" : "ntt_fwd_cols";
+#define COLS_CASE(LR)                                                                            \
+  case LR: {                                                                                     \
+    dim3 grid(256 / ColCfg<LR>::CT, nl, batch), block(ColCfg<LR>::THREADS);                      \
+    LAUNCH(c, name, (ntt_cols_kernel<SP, INV, LR>), grid, block, a);                             \
+    break;                                                                                       \
+  }
+  switch (c->logR) {
+    COLS_CASE(2) COLS_CASE(3) COLS_CASE(4) COLS_CASE(5) COLS_CASE(6) COLS_CASE(7) COLS_CASE(8)
+    default: FAIL(c, FHE_HIP_ERR_RANGE, "unsupported logN");
+  }
+#undef COLS_CASE
+  return FHE_HIP_OK;
+}
+
+template <bool SP, bool INV>
+int launch_rows(fhe_hip_ctx *c, const NttArgs &a, u32 nl, u32 batch) {
+  const u32 R = 1u << c->logR, rows = R < 16 ? R : 16;
+  dim3 grid(R / rows, nl, batch), block(16 * rows);
+  LAUNCH(c, INV ? "ntt_inv_rows" : "ntt_fwd_rows", (ntt_rows_kernel<SP, INV>), grid, block, a);
+  return FHE_HIP_OK;
+}
+
+template <bool SP>
+int ntt_run_sp(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
+  if (p.nl == 0 || p.batch == 0) return FHE_HIP_OK;
+  NttArgs a;
+  a.tw = inverse ? c->d_tw_inv : c->d_tw_fwd;
+  a.primes = c->d_primes; a.midx = p.midx; a.mdiv = p.mdiv; a.mper = p.mper;
+  a.logN = c->logN; a.logR = c->logR;
+  a.dst = p.dst; a.dst_bstride = p.dst_bstride;
+  // first pass reads the (possibly broadcast) source, second pass runs in place on dst
+  NttArgs first = a, second = a;
+  first.src = p.src; first.src_bstride = p.src_bstride; first.smod = p.smod;
+  second.src = p.dst; second.src_bstride = p.dst_bstride; second.smod = p.nl;
+  if (!inverse) {
+    TRY((launch_cols<SP, false>(c, first, p.nl, p.batch)));
+    TRY((launch_rows<SP, false>(c, second, p.nl, p.batch)));
+  } else {
+    TRY((launch_rows<SP, true>(c, first, p.nl, p.batch)));
+    TRY((launch_cols<SP, true>(c, second, p.nl, p.batch)));
+  }
+  return FHE_HIP_OK;
+}
+
+int ntt_run(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
+  // grid.y / grid.z limits: split large limb counts over several launches
+  if (p.nl > 65535 || p.batch > 65535) FAIL(c, FHE_HIP_ERR_RANGE, "too many limbs in one NTT launch");
+  return c->sp ? ntt_run_sp<true>(c, p, inverse) : ntt_run_sp<false>(c, p, inverse);
+}
+
+// in-place NTT of nl limbs per entry using the identity modulus map (limb k -> modulus first+k)
+int ntt_simple(fhe_hip_ctx *c, u64 *data, const u32 *midx, u32 nl, u32 batch, u64 bstride, bool inverse) {
+  NttPlan p{data, data, midx, 1, nl, nl, nl, batch, bstride, bstride};
+  return ntt_run(c, p, inverse);
+}
+
+dim3 pw_grid(const fhe_hip_ctx *c, u32 y, u32 z) { return dim3((unsigned)(c->N / (2 * PW_THREADS)), y, z); }
+
+// ---- staging of host buffers ---------------------------------------------------------------------
+struct Staged {
+  fhe_hip_ctx *c; int kind;
+  struct Out { void *host; void *dev; size_t bytes; };
+  std::vector<Out> outs;
+  int next = 0;
+  Staged(fhe_hip_ctx *ctx, int mem_kind) : c(ctx), kind(mem_kind) {}
+  // returns device pointer for an input
+  int in(const void *p, size_t bytes, const u64 **dev) {
+    if (kind == FHE_HIP_MEM_DEVICE) { *dev = (const u64 *)p; return FHE_HIP_OK; }
+    int slot = next++;
+    TRY(ensure_stage(c, slot, bytes));
+    HIPCHK(c, hipMemcpyAsync(c->stage[slot], p, bytes, hipMemcpyHostToDevice, c->stream));
+    *dev = (const u64 *)c->stage[slot];
+    return FHE_HIP_OK;
+  }
+  int out(void *p, size_t bytes, u64 **dev, bool also_in) {
+    if (kind == FHE_HIP_MEM_DEVICE) { *dev = (u64 *)p; return FHE_HIP_OK; }
+    int slot = next++;
+    TRY(ensure_stage(c, slot, bytes));
+    if (also_in) HIPCHK(c, hipMemcpyAsync(c->stage[slot], p, bytes, hipMemcpyHostToDevice, c->stream));
+    *dev = (u64 *)c->stage[slot];
+    outs.push_back({p, c->stage[slot], bytes});
+    return FHE_HIP_OK;
+  }
+  int finish() {
+    if (kind == FHE_HIP_MEM_DEVICE) return FHE_HIP_OK;
+    for (auto &o : outs) HIPCHK(c, hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FHE_HIP_OK;
+  }
+};
+
+int check_ctx(fhe_hip_ctx *c) {
+  if (!c) return FHE_HIP_ERR_ARG;
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) { c->err = std::string("hipSetDevice: ") + hipGetErrorString(e); return FHE_HIP_ERR_HIP; }
+  return FHE_HIP_OK;
+}
+
+// ---- device pipelines (all pointers device) ------------------------------------------------------
+
+// BaseConverter::approximated_mod_up body on device: special limbs of rop from power-basis op
+int dev_conv_to_special(fhe_hip_ctx *c, u64 *rop, u32 rop_limbs, u32 rop_off, const u64 *op, u32 op_limbs, u32 Li, u32 batch) {
+  BconvArgs a;
+  a.out = rop; a.src = op;
+  a.inv_m = c->d_hat_qj_inv_m + (size_t)(Li - 2) * c->L;
+  a.hat_m = c->d_hat_qj_pi_m + (size_t)(Li - 2) * c->K * c->L;
+  a.primes = c->d_primes;
+  a.nsrc = Li; a.src_first = 0; a.src_limbs = op_limbs; a.src_off = 0;
+  a.tgt_first = c->L; a.out_limbs = rop_limbs; a.out_off = rop_off; a.hat_stride = c->L;
+  a.N = c->N;
+  LAUNCH_SP(c, "bconv_modup", bconv_kernel, pw_grid(c, c->K, batch), dim3(PW_THREADS), a);
+  return FHE_HIP_OK;
+}
+// neg_approx_convert_to_normal_basis for j < L0: special limbs (power basis) at limb offset sp_off of op
+int dev_conv_to_normal(fhe_hip_ctx *c, u64 *rop, u32 L0, const u64 *op, u32 op_limbs, u32 sp_off, u32 batch) {
+  BconvArgs a;
+  a.out = rop; a.src = op;
+  a.inv_m = c->d_hat_pi_inv_m;
+  a.hat_m = c->d_neg_hat_pi_qj_m;
+  a.primes = c->d_primes;
+  a.nsrc = c->K; a.src_first = c->L; a.src_limbs = op_limbs; a.src_off = sp_off;
+  a.tgt_first = 0; a.out_limbs = L0; a.out_off = 0; a.hat_stride = c->K;
+  a.N = c->N;
+  LAUNCH_SP(c, "bconv_moddown", bconv_kernel, pw_grid(c, L0, batch), dim3(PW_THREADS), a);
+  return FHE_HIP_OK;
+}
+
+// approximated_mod_down: op [e][L0+K][N] -> rop [e][L0][N]; optional addend [e][L0][N]
+int dev_mod_down(fhe_hip_ctx *c, u64 *rop, const u64 *op, u32 L0, u32 batch, const u64 *addend, int ws_slot) {
+  const size_t bytes = (size_t)batch * L0 * c->N * 8;
+  TRY(ensure_ws(c, ws_slot, bytes));
+  u64 *conv = (u64 *)c->ws[ws_slot];
+  TRY(dev_conv_to_normal(c, conv, L0, op, L0 + c->K, L0, batch));
+  TRY(ntt_simple(c, conv, c->d_iota, L0, batch, (u64)L0 * c->N, false));
+  LAUNCH_SP(c, "moddown_final", moddown_final_kernel, pw_grid(c, L0, batch), dim3(PW_THREADS), rop, op, (const u64 *)conv, addend,
+            (const u64 *)c->d_Pinv_qj_m, (const PrimeC *)c->d_primes, L0, L0 + c->K, c->N);
+  return FHE_HIP_OK;
+}
+
+// BaseConverter::rescale: op [e][n][N] (last limb power basis) -> rop [e][n-1][N]
+int dev_rescale(fhe_hip_ctx *c, u64 *rop, const u64 *op, u32 n, u32 entries, int ws_slot) {
+  const u64 N = c->N;
+  TRY(ensure_ws(c, ws_slot, (size_t)entries * (n - 1) * N * 8));
+  u64 *tail = (u64 *)c->ws[ws_slot];
+  // tail[e][j] = NTT_j(op[e][n-1]) for j < n-1 (src limb broadcast: smod = 1 from the last limb)
+  NttPlan p{op + (size_t)(n - 1) * N, tail, c->d_iota, 1, n - 1, 1, n - 1, entries, (u64)n * N, (u64)(n - 1) * N};
+  TRY(ntt_run(c, p, false));
+  LAUNCH_SP(c, "rescale", rescale_kernel, pw_grid(c, n - 1, entries), dim3(PW_THREADS), rop, op, (const u64 *)tail,
+            (const u64 *)(c->d_qinv_m + (size_t)(n - 1) * c->M), (const PrimeC *)c->d_primes, n, N);
+  return FHE_HIP_OK;
+}
+
+// Mul::reLinearize: ct3 [b][3][Li][N] -> out [b][2][Li][N]
+int dev_relin(fhe_hip_ctx *c, u64 *out, const u64 *ct3, u32 Li, u32 batch) {
+  const u64 N = c->N;
+  if (!c->d_mk_beta) FAIL(c, FHE_HIP_ERR_NOKEY, "mult key not loaded");
+  // bound the Li^2 intermediate: process the batch in chunks of at most ~2 GiB
+  const size_t per_ct = (size_t)Li * Li * N * 8;
+  u32 chunk = (u32)((2ull << 30) / per_ct);
+  if (chunk < 1) chunk = 1;
+  if (chunk > batch) chunk = batch;
+  TRY(ensure_ws(c, 0, (size_t)chunk * Li * N * 8));
+  TRY(ensure_ws(c, 1, (size_t)chunk * per_ct));
+  u64 *pw = (u64 *)c->ws[0], *t = (u64 *)c->ws[1];
+  for (u32 b0 = 0; b0 < batch; b0 += chunk) {
+    const u32 nb = (batch - b0 < chunk) ? batch - b0 : chunk;
+    const u64 *in = ct3 + (size_t)b0 * 3 * Li * N;
+    // ct2_power = INTT(ct[2])   (evaluator.cpp:659-660)
+    NttPlan pi{in + (size_t)2 * Li * N, pw, c->d_iota, 1, Li, Li, Li, nb, (u64)3 * Li * N, (u64)Li * N};
+    TRY(ntt_run(c, pi, true));
+    // t[i][j] = NTT_i(ct2_power[j])   (evaluator.cpp:666-668), limb id = i*Li + j
+    NttPlan pf{pw, t, c->d_iota, Li, Li, Li, Li * Li, nb, (u64)Li * N, (u64)Li * Li * N};
+    TRY(ntt_run(c, pf, false));
+    LAUNCH_SP(c, "relin_mac", relin_mac_kernel, pw_grid(c, Li, nb), dim3(PW_THREADS), out + (size_t)b0 * 2 * Li * N, (const u64 *)t, in,
+              (const u64 *)c->d_mk_beta, (const u64 *)c->d_mk_alpha, (const PrimeC *)c->d_primes, Li, c->L, N);
+  }
+  return FHE_HIP_OK;
+}
+
+// Mul::rescale_ntt: ct [b][2][Li][N] (modified: last limbs go to the power basis) -> out [b][2][Li-1][N]
+int dev_rescale_ntt(fhe_hip_ctx *c, u64 *out, u64 *ct, u32 Li, u32 batch) {
+  const u64 N = c->N;
+  // INTT of the last limb of each half (evaluator.cpp:707): entries = 2*batch polys of Li limbs
+  NttPlan pi{ct + (size_t)(Li - 1) * N, ct + (size_t)(Li - 1) * N, c->d_iota + (Li - 1), 1, 1, 1, 1, 2 * batch, (u64)Li * N, (u64)Li * N};
+  TRY(ntt_run(c, pi, true));
+  return dev_rescale(c, out, ct, Li, 2 * batch, 2);
+}
+
+int dev_mul_relin_rescale(fhe_hip_ctx *c, u64 *out, const u64 *c0, const u64 *c1, u32 Li, u32 batch) {
+  const u64 N = c->N;
+  TRY(ensure_ws(c, 3, (size_t)batch * 3 * Li * N * 8));
+  TRY(ensure_ws(c, 4, (size_t)batch * 2 * Li * N * 8));
+  u64 *ct3 = (u64 *)c->ws[3], *rl = (u64 *)c->ws[4];
+  LAUNCH_SP(c, "cross_mult", cross_mult_kernel, pw_grid(c, Li, batch), dim3(PW_THREADS), ct3, c0, c1, (const PrimeC *)c->d_primes, Li, N);
+  TRY(dev_relin(c, rl, ct3, Li, batch));
+  return dev_rescale_ntt(c, out, rl, Li, batch);
+}
+
+int get_galois_perm(fhe_hip_ctx *c, u64 galois, u32 **perm) {
+  auto it = c->galois_perm.find(galois);
+  if (it != c->galois_perm.end()) { *perm = it->second; return FHE_HIP_OK; }
+  u32 *d = nullptr;
+  HIPCHK(c, hipMalloc((void **)&d, c->N * sizeof(u32)));
+  LAUNCH(c, "galois_perm", galois_perm_kernel, dim3((unsigned)((c->N + 255) / 256)), dim3(256), d, c->logN, galois);
+  c->galois_perm[galois] = d;
+  *perm = d;
+  return FHE_HIP_OK;
+}
+
+// rotate_slots_inplace + apply_rotation_key (evaluator.cpp:299-311, 343-399); ct = [b][2][Li][N] in place
+int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch) {
+  const u64 N = c->N; const u32 K = c->K, nl = Li + K;
+  auto it = c->rot_keys.find(galois);
+  if (it == c->rot_keys.end()) FAIL(c, FHE_HIP_ERR_NOKEY, "rotation key not loaded for this galois element");
+  u32 *perm = nullptr;
+  const bool identity = (galois == 1);
+  const size_t ctb = (size_t)batch * 2 * Li * N * 8, extb = (size_t)batch * nl * N * 8;
+  TRY(ensure_ws(c, 3, ctb));       // g = galois(ct): [b][2][Li][N]
+  TRY(ensure_ws(c, 4, extb));      // ext / e0
+  TRY(ensure_ws(c, 5, extb));      // e1
+  TRY(ensure_ws(c, 0, (size_t)batch * Li * N * 8));  // power-basis copy of ax_g
+  u64 *g = (u64 *)c->ws[3], *e0 = (u64 *)c->ws[4], *e1 = (u64 *)c->ws[5], *pw = (u64 *)c->ws[0];
+  if (identity) {
+    HIPCHK(c, hipMemcpyAsync(g, ct, ctb, hipMemcpyDeviceToDevice, c->stream));
+  } else {
+    TRY(get_galois_perm(c, galois, &perm));
+    LAUNCH(c, "galois_gather", galois_gather_kernel, dim3((unsigned)(N / PW_THREADS), 2 * Li, batch), dim3(PW_THREADS), g, (const u64 *)ct,
+           (const u32 *)perm, N);
+  }
+  // power basis of ax_g (d[1]->backward(), :360)
+  NttPlan pi{g + (size_t)Li * N, pw, c->d_iota, 1, Li, Li, Li, batch, (u64)2 * Li * N, (u64)Li * N};
+  TRY(ntt_run(c, pi, true));
+  // mod up: special limbs from the power basis; normal limbs of the NTT-domain result are ax_g itself
+  // (NTT(INTT(x)) = x for canonical x, so the Li forward NTTs of :363-366 are not recomputed)
+  TRY(dev_conv_to_special(c, e0, nl, Li, pw, Li, Li, batch));
+  for (u32 b = 0; b < batch; ++b)
+    HIPCHK(c, hipMemcpyAsync(e0 + (size_t)b * nl * N, g + ((size_t)b * 2 + 1) * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream));
+  {  // forward NTT of the K special limbs
+    NttPlan pf{e0 + (size_t)Li * N, e0 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
+    TRY(ntt_run(c, pf, false));
+  }
+  const u32 *rotmap = c->d_rotmap + (size_t)Li * c->M;
+  LAUNCH_SP(c, "rot_keymul", rot_keymul_kernel, pw_grid(c, nl, batch), dim3(PW_THREADS), e0, e1, (const u64 *)e0, (const u64 *)it->second.beta_m,
+            (const u64 *)it->second.alpha_m, (const PrimeC *)c->d_primes, rotmap, nl, N);
+  {  // special limbs back to the power basis (:386-392)
+    NttPlan p0{e0 + (size_t)Li * N, e0 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
+    TRY(ntt_run(c, p0, true));
+    NttPlan p1{e1 + (size_t)Li * N, e1 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
+    TRY(ntt_run(c, p1, true));
+  }
+  // mod down both halves into ct; rop[0] += galois(bx) (:394-398).  Output halves are strided [b][2][Li][N]:
+  // run per half with entry stride handled by a temporary contiguous buffer.
+  TRY(ensure_ws(c, 1, (size_t)batch * Li * N * 8 * 2));
+  u64 *o0 = (u64 *)c->ws[1], *o1 = o0 + (size_t)batch * Li * N;
+  // addend for half 0 = bx_g, gathered contiguously
+  TRY(ensure_ws(c, 2, (size_t)batch * Li * N * 8 * 2));
+  u64 *bxg = (u64 *)c->ws[2], *conv = bxg + (size_t)batch * Li * N;
+  for (u32 b = 0; b < batch; ++b)
+    HIPCHK(c, hipMemcpyAsync(bxg + (size_t)b * Li * N, g + (size_t)b * 2 * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream));
+  for (int h = 0; h < 2; ++h) {
+    const u64 *op = h == 0 ? e0 : e1;
+    u64 *rop = h == 0 ? o0 : o1;
+    TRY(dev_conv_to_normal(c, conv, Li, op, nl, Li, batch));
+    TRY(ntt_simple(c, conv, c->d_iota, Li, batch, (u64)Li * N, false));
+    LAUNCH_SP(c, "moddown_final", moddown_final_kernel, pw_grid(c, Li, batch), dim3(PW_THREADS), rop, op, (const u64 *)conv,
+              (const u64 *)(h == 0 ? bxg : nullptr), (const u64 *)c->d_Pinv_qj_m, (const PrimeC *)c->d_primes, Li, nl, N);
+  }
+  for (u32 b = 0; b < batch; ++b) {
+    HIPCHK(c, hipMemcpyAsync(ct + (size_t)b * 2 * Li * N, o0 + (size_t)b * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ct + ((size_t)b * 2 + 1) * Li * N, o1 + (size_t)b * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream));
+  }
+  return FHE_HIP_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C-ABI
+// =====================================================================================================
+extern "C" {
+
+const char *fhe_hip_last_error(const fhe_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int fhe_hip_ctx_create(fhe_hip_ctx **out, uint32_t logN, uint32_t L, uint32_t K, const uint64_t *primes, const uint64_t *psi, int device) {
+  if (!out || !primes || !psi) { g_create_error = "null argument"; return FHE_HIP_ERR_ARG; }
+  *out = nullptr;
+  if (logN < 10 || logN > 16) { g_create_error = "logN must be in [10, 16]"; return FHE_HIP_ERR_RANGE; }
+  if (L < 1 || L + K > 255) { g_create_error = "need 1 <= L and L + K <= 255"; return FHE_HIP_ERR_RANGE; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    g_create_error = "no usable HIP device (this library has no CPU fallback)";
+    return FHE_HIP_ERR_NODEVICE;
+  }
+  fhe_hip_ctx *c = new fhe_hip_ctx();
+  auto fail = [&](int rc) { g_create_error = c->err; fhe_hip_ctx_destroy(c); return rc; };
+  c->device = device; c->logN = logN; c->L = L; c->K = K; c->M = L + K; c->N = 1ull << logN; c->logR = logN - 8;
+  const uint32_t M = c->M; const u64 N = c->N;
+  if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(FHE_HIP_ERR_HIP); }
+  c->primes.assign(primes, primes + M);
+  c->sp = true;
+  for (uint32_t m = 0; m < M; ++m) {
+    const u64 p = primes[m];
+    if (p >= (1ull << 62) || p < (1ull << 20) || (p - 1) % (2 * N) != 0) { c->err = "prime out of contract (p < 2^62, 2N | p-1)"; return fail(FHE_HIP_ERR_RANGE); }
+    if (h_powmod(psi[m], N, p) != p - 1) { c->err = "psi is not a primitive 2N-th root of unity"; return fail(FHE_HIP_ERR_RANGE); }
+    if ((p & 0xFFFFFFFFull) != 1) c->sp = false;
+  }
+  std::vector<PrimeC> pc(M);
+  std::vector<u64> twf((size_t)M * N), twi((size_t)M * N);
+  for (uint32_t m = 0; m < M; ++m) {
+    const u64 p = primes[m];
+    PrimeC &P = pc[m];
+    P.p = p; P.twop = 2 * p; P.p1 = (u32)(p >> 32); P.pad = 0;
+    u64 inv = 1;  // Newton iteration for p^-1 mod 2^64
+    for (int i = 0; i < 6; ++i) inv *= 2 - p * inv;
+    P.pinv = inv;
+    P.r2 = (u64)((((u128)h_to_mont(1, p)) << 64) % p);
+    P.ninv_m = h_to_mont(h_invmod(N % p, p), p);
+    const u64 ps = psi[m] % p, psinv = h_invmod(ps, p);
+    u64 f = h_to_mont(1, p), g = f;  // running powers kept in Montgomery form
+    for (size_t k = 0; k < N; ++k) {
+      const size_t r = h_brv(k, logN);
+      twf[(size_t)m * N + r] = f; twi[(size_t)m * N + r] = g;
+      f = h_mulmod(f, ps, p); g = h_mulmod(g, psinv, p);
+    }
+  }
+  int rc;
+  if ((rc = upload(c, &c->d_primes, pc)) || (rc = upload(c, &c->d_tw_fwd, twf)) || (rc = upload(c, &c->d_tw_inv, twi))) return fail(rc);
+  std::vector<u32> iota(M), rotmap((size_t)(L + 1) * M, 0);
+  for (uint32_t m = 0; m < M; ++m) iota[m] = m;
+  for (uint32_t Li = 0; Li <= L; ++Li)
+    for (uint32_t cm = 0; cm < Li + K && cm < M; ++cm) rotmap[(size_t)Li * M + cm] = cm < Li ? cm : L + (cm - Li);  // evaluator.cpp:374
+  if ((rc = upload(c, &c->d_iota, iota)) || (rc = upload(c, &c->d_rotmap, rotmap))) return fail(rc);
+  // BaseConverter tables (base_converter.cpp:122-187), stored in Montgomery form of the prime they multiply under
+  const std::vector<u64> &P = c->primes;
+  std::vector<u64> hat_pi_inv(K), neg_hat((size_t)L * K), Pinv(L);
+  const size_t Lm1 = L > 1 ? L - 1 : 0;
+  std::vector<u64> hat_qj_inv(Lm1 * L, 0), hat_qj_pi(Lm1 * K * L, 0), qinv((size_t)M * M, 0);
+  for (uint32_t k = 0; k < K; ++k) {
+    const uint32_t cm = L + k;
+    hat_pi_inv[k] = h_to_mont(h_invmod(h_product_of(P, L, K, (int)k, cm), P[cm]), P[cm]);
+    for (uint32_t l = 0; l < L; ++l) neg_hat[(size_t)l * K + k] = h_to_mont(P[l] - h_product_of(P, L, K, (int)k, l), P[l]);
+  }
+  for (uint32_t n = 2; n <= L; ++n) {
+    const uint32_t l = n - 2;
+    for (uint32_t j = 0; j < n; ++j) hat_qj_inv[(size_t)l * L + j] = h_to_mont(h_invmod(h_product_of(P, 0, n, (int)j, j), P[j]), P[j]);
+    for (uint32_t k = 0; k < K; ++k)
+      for (uint32_t j = 0; j < n; ++j) hat_qj_pi[((size_t)l * K + k) * L + j] = h_to_mont(h_product_of(P, 0, n, (int)j, L + k), P[L + k]);
+  }
+  for (uint32_t j = 0; j < L; ++j) Pinv[j] = h_to_mont(h_invmod(h_product_of(P, L, K, -1, j), P[j]), P[j]);
+  for (uint32_t a = 0; a < M; ++a)
+    for (uint32_t j = 0; j < M; ++j)
+      if (a != j) qinv[(size_t)a * M + j] = h_to_mont(h_invmod(P[a] % P[j], P[j]), P[j]);  // math::inv_mod_prime(P[a], j), base_converter.cpp:261
+  if ((rc = upload(c, &c->d_hat_pi_inv_m, hat_pi_inv)) || (rc = upload(c, &c->d_neg_hat_pi_qj_m, neg_hat)) || (rc = upload(c, &c->d_Pinv_qj_m, Pinv)) ||
+      (rc = upload(c, &c->d_hat_qj_inv_m, hat_qj_inv)) || (rc = upload(c, &c->d_hat_qj_pi_m, hat_qj_pi)) || (rc = upload(c, &c->d_qinv_m, qinv)))
+    return fail(rc);
+  *out = c;
+  return FHE_HIP_OK;
+}
+
+void fhe_hip_ctx_destroy(fhe_hip_ctx *c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  prof_drain(c);
+  void *ptrs[] = {c->d_primes, c->d_tw_fwd, c->d_tw_inv, c->d_iota, c->d_rotmap, c->d_hat_pi_inv_m, c->d_neg_hat_pi_qj_m, c->d_Pinv_qj_m,
+                  c->d_hat_qj_inv_m, c->d_hat_qj_pi_m, c->d_qinv_m, c->d_mk_beta, c->d_mk_alpha};
+  for (void *p : ptrs) if (p) hipFree(p);
+  for (auto &kv : c->rot_keys) { hipFree(kv.second.beta_m); hipFree(kv.second.alpha_m); }
+  for (auto &kv : c->galois_perm) hipFree(kv.second);
+  for (void *p : c->ws) if (p) hipFree(p);
+  for (void *p : c->stage) if (p) hipFree(p);
+  delete c;
+}
+
+int fhe_hip_set_stream(fhe_hip_ctx *c, void *s) { TRY(check_ctx(c)); c->stream = (hipStream_t)s; return FHE_HIP_OK; }
+int fhe_hip_sync(fhe_hip_ctx *c) { TRY(check_ctx(c)); HIPCHK(c, hipStreamSynchronize(c->stream)); return FHE_HIP_OK; }
+
+static int ntt_api(fhe_hip_ctx *c, uint64_t *limbs, const uint32_t *moduli_idx, size_t n_limbs, int mem_kind, bool inverse) {
+  TRY(check_ctx(c));
+  if (!limbs || !moduli_idx) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  for (size_t i = 0; i < n_limbs; ++i) if (moduli_idx[i] >= c->M) FAIL(c, FHE_HIP_ERR_RANGE, "moduli_idx out of range");
+  if (n_limbs == 0) return FHE_HIP_OK;
+  Staged st(c, mem_kind);
+  u64 *d = nullptr;
+  TRY(st.out(limbs, n_limbs * c->N * 8, &d, true));
+  TRY(ensure_stage(c, 3, n_limbs * sizeof(u32)));
+  u32 *dm = (u32 *)c->stage[3];
+  HIPCHK(c, hipMemcpyAsync(dm, moduli_idx, n_limbs * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+  for (size_t off = 0; off < n_limbs; off += 32768) {
+    const u32 n = (u32)((n_limbs - off < 32768) ? n_limbs - off : 32768);
+    NttPlan p{d + off * c->N, d + off * c->N, dm + off, 1, n, n, n, 1, 0, 0};
+    TRY(ntt_run(c, p, inverse));
+  }
+  return st.finish();
+}
+int fhe_hip_ntt_forward(fhe_hip_ctx *c, uint64_t *limbs, const uint32_t *idx, size_t n, int mk) { return ntt_api(c, limbs, idx, n, mk, false); }
+int fhe_hip_ntt_backward(fhe_hip_ctx *c, uint64_t *limbs, const uint32_t *idx, size_t n, int mk) { return ntt_api(c, limbs, idx, n, mk, true); }
+
+static int galois_api(fhe_hip_ctx *c, uint64_t *polys, uint32_t nlimbs, uint64_t galois, size_t batch, int mem_kind, bool ntt_domain) {
+  TRY(check_ctx(c));
+  if (!polys) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (!(galois & 1) || galois >= 2 * c->N) FAIL(c, FHE_HIP_ERR_ARG, "galois must be odd and < 2N");
+  if (nlimbs == 0 || nlimbs > c->M) FAIL(c, FHE_HIP_ERR_RANGE, "bad limb count");
+  if (galois == 1 || batch == 0) return FHE_HIP_OK;  // src/yell.cpp:8-9
+  const size_t bytes = batch * nlimbs * c->N * 8;
+  Staged st(c, mem_kind);
+  u64 *d = nullptr;
+  TRY(st.out(polys, bytes, &d, true));
+  TRY(ensure_ws(c, 0, bytes));
+  u64 *tmp = (u64 *)c->ws[0];
+  HIPCHK(c, hipMemcpyAsync(tmp, d, bytes, hipMemcpyDeviceToDevice, c->stream));
+  dim3 grid((unsigned)(c->N / PW_THREADS), nlimbs, (unsigned)batch);
+  if (ntt_domain) {
+    u32 *perm = nullptr;
+    TRY(get_galois_perm(c, galois, &perm));
+    LAUNCH(c, "galois_gather", galois_gather_kernel, grid, dim3(PW_THREADS), d, (const u64 *)tmp, (const u32 *)perm, c->N);
+  } else {
+    LAUNCH(c, "galois_coeff", galois_coeff_kernel, grid, dim3(PW_THREADS), d, (const u64 *)tmp, (const PrimeC *)c->d_primes, c->logN, galois);
+  }
+  return st.finish();
+}
+int fhe_hip_apply_galois(fhe_hip_ctx *c, uint64_t *p, uint32_t nl, uint64_t g, size_t b, int mk) { return galois_api(c, p, nl, g, b, mk, true); }
+int fhe_hip_apply_galois_non_ntt(fhe_hip_ctx *c, uint64_t *p, uint32_t nl, uint64_t g, size_t b, int mk) { return galois_api(c, p, nl, g, b, mk, false); }
+
+int fhe_hip_mod_up(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t Li, size_t batch, int mem_kind) {
+  TRY(check_ctx(c));
+  if (!rop || !op) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (Li > c->L) FAIL(c, FHE_HIP_ERR_RANGE, "Only support mod up from normal primes");
+  if (Li <= 1) FAIL(c, FHE_HIP_ERR_RANGE, "nmoduli <= 1");  // base_converter.cpp:284-285
+  if (batch == 0) return FHE_HIP_OK;
+  const u64 N = c->N; const u32 nl = Li + c->K;
+  Staged st(c, mem_kind);
+  const u64 *dop = nullptr; u64 *drop = nullptr;
+  TRY(st.in(op, batch * Li * N * 8, &dop));
+  TRY(st.out(rop, batch * nl * N * 8, &drop, false));
+  for (size_t b = 0; b < batch; ++b)
+    HIPCHK(c, hipMemcpyAsync(drop + b * nl * N, dop + b * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream));
+  TRY(dev_conv_to_special(c, drop, nl, Li, dop, Li, Li, (u32)batch));
+  return st.finish();
+}
+
+int fhe_hip_mod_down(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t L0, size_t batch, int mem_kind) {
+  TRY(check_ctx(c));
+  if (!rop || !op) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (L0 < 1 || L0 > c->L || c->K < 1) FAIL(c, FHE_HIP_ERR_RANGE, "bad limb count");
+  if (batch == 0) return FHE_HIP_OK;
+  const u64 N = c->N;
+  Staged st(c, mem_kind);
+  const u64 *dop = nullptr; u64 *drop = nullptr;
+  TRY(st.in(op, batch * (L0 + c->K) * N * 8, &dop));
+  TRY(st.out(rop, batch * L0 * N * 8, &drop, false));
+  TRY(dev_mod_down(c, drop, dop, L0, (u32)batch, nullptr, 2));
+  return st.finish();
+}
+
+int fhe_hip_rescale(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t n, size_t batch, int mem_kind) {
+  TRY(check_ctx(c));
+  if (!rop || !op) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (n < 2 || n > c->M) FAIL(c, FHE_HIP_ERR_RANGE, "Already in the last moduli.");
+  if (batch == 0) return FHE_HIP_OK;
+  const u64 N = c->N;
+  Staged st(c, mem_kind);
+  const u64 *dop = nullptr; u64 *drop = nullptr;
+  TRY(st.in(op, batch * n * N * 8, &dop));
+  TRY(st.out(rop, batch * (n - 1) * N * 8, &drop, false));
+  TRY(dev_rescale(c, drop, dop, n, (u32)batch, 2));
+  return st.finish();
+}
+
+static int load_key(fhe_hip_ctx *c, u64 **dst, const uint64_t *src, size_t limbs, const u32 *midx, u32 mper, int mem_kind) {
+  const size_t bytes = limbs * c->N * 8;
+  if (!*dst) HIPCHK(c, hipMalloc((void **)dst, bytes));
+  HIPCHK(c, hipMemcpyAsync(*dst, src, bytes, mem_kind == FHE_HIP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+  LAUNCH_SP(c, "to_mont", to_mont_kernel, pw_grid(c, (u32)limbs, 1), dim3(PW_THREADS), *dst, (const PrimeC *)c->d_primes, midx, mper, c->N);
+  return FHE_HIP_OK;
+}
+
+int fhe_hip_load_mult_key(fhe_hip_ctx *c, const uint64_t *beta, const uint64_t *alpha, int mem_kind) {
+  TRY(check_ctx(c));
+  if (!beta || !alpha) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  // [L][L][N]: limb id = j*L + i uses modulus i = id % L
+  TRY(load_key(c, &c->d_mk_beta, beta, (size_t)c->L * c->L, c->d_iota, c->L, mem_kind));
+  TRY(load_key(c, &c->d_mk_alpha, alpha, (size_t)c->L * c->L, c->d_iota, c->L, mem_kind));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return FHE_HIP_OK;
+}
+
+int fhe_hip_load_rot_key(fhe_hip_ctx *c, uint64_t galois, const uint64_t *beta, const uint64_t *alpha, int mem_kind) {
+  TRY(check_ctx(c));
+  if (!beta || !alpha) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (c->K < 1) FAIL(c, FHE_HIP_ERR_RANGE, "rotation keys need special primes");
+  if (galois != 0 && (!(galois & 1) || galois >= 2 * c->N)) FAIL(c, FHE_HIP_ERR_ARG, "galois must be odd and < 2N");
+  RotKeyDev &rk = c->rot_keys[galois];
+  TRY(load_key(c, &rk.beta_m, beta, c->M, c->d_iota, c->M, mem_kind));
+  TRY(load_key(c, &rk.alpha_m, alpha, c->M, c->d_iota, c->M, mem_kind));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return FHE_HIP_OK;
+}
+
+int fhe_hip_add(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t nlimbs, size_t batch, int mem_kind) {
+  TRY(check_ctx(c));
+  if (!rop || !op) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (nlimbs < 1 || nlimbs > c->M) FAIL(c, FHE_HIP_ERR_RANGE, "bad limb count");
+  if (batch == 0) return FHE_HIP_OK;
+  const size_t bytes = batch * nlimbs * c->N * 8;
+  Staged st(c, mem_kind);
+  const u64 *dop = nullptr; u64 *drop = nullptr;
+  TRY(st.in(op, bytes, &dop));
+  TRY(st.out(rop, bytes, &drop, true));
+  LAUNCH(c, "add", add_kernel, pw_grid(c, nlimbs, (u32)batch), dim3(PW_THREADS), drop, dop, (const PrimeC *)c->d_primes, c->N);
+  return st.finish();
+}
+
+int fhe_hip_multiply_plain(fhe_hip_ctx *c, uint64_t *ct, const uint64_t *pt, uint32_t nlimbs, size_t batch, int mem_kind) {
+  TRY(check_ctx(c));
+  if (!ct || !pt) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (nlimbs < 1 || nlimbs > c->M) FAIL(c, FHE_HIP_ERR_RANGE, "bad limb count");
+  if (batch == 0) return FHE_HIP_OK;
+  Staged st(c, mem_kind);
+  const u64 *dpt = nullptr; u64 *dct = nullptr;
+  TRY(st.in(pt, (size_t)nlimbs * c->N * 8, &dpt));
+  TRY(st.out(ct, batch * 2 * nlimbs * c->N * 8, &dct, true));
+  LAUNCH_SP(c, "mul_plain", mul_plain_kernel, pw_grid(c, 2 * nlimbs, (u32)batch), dim3(PW_THREADS), dct, dpt, (const PrimeC *)c->d_primes, nlimbs, c->N);
+  return st.finish();
+}
+
+static int check_li(fhe_hip_ctx *c, uint32_t Li, uint32_t min) {
+  if (Li > c->L) FAIL(c, FHE_HIP_ERR_RANGE, "Too many moduli.");
+  if (Li < min) FAIL(c, FHE_HIP_ERR_RANGE, "too few moduli");
+  return FHE_HIP_OK;
+}
+
+int fhe_hip_cross_mult(fhe_hip_ctx *c, uint64_t *out3, const uint64_t *c0, const uint64_t *c1, uint32_t Li, size_t batch, int mem_kind) {
+  TRY(check_ctx(c));
+  if (!out3 || !c0 || !c1) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  TRY(check_li(c, Li, 1));
+  if (batch == 0) return FHE_HIP_OK;
+  const size_t ctb = batch * 2 * Li * c->N * 8;
+  Staged st(c, mem_kind);
+  const u64 *d0 = nullptr, *d1 = nullptr; u64 *dout = nullptr;
+  TRY(st.in(c0, ctb, &d0)); TRY(st.in(c1, ctb, &d1));
+  TRY(st.out(out3, ctb / 2 * 3, &dout, false));
+  LAUNCH_SP(c, "cross_mult", cross_mult_kernel, pw_grid(c, Li, (u32)batch), dim3(PW_THREADS), dout, d0, d1, (const PrimeC *)c->d_primes, Li, c->N);
+  return st.finish();
+}
+
+int fhe_hip_relin_only(fhe_hip_ctx *c, uint64_t *out, const uint64_t *ct3, uint32_t Li, size_t batch, int mem_kind) {
+  TRY(check_ctx(c));
+  if (!out || !ct3) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  TRY(check_li(c, Li, 1));
+  if (batch == 0) return FHE_HIP_OK;
+  const size_t limb_b = (size_t)Li * c->N * 8;
+  Staged st(c, mem_kind);
+  const u64 *din = nullptr; u64 *dout = nullptr;
+  TRY(st.in(ct3, batch * 3 * limb_b, &din));
+  TRY(st.out(out, batch * 2 * limb_b, &dout, false));
+  TRY(dev_relin(c, dout, din, Li, (u32)batch));
+  return st.finish();
+}
+
+int fhe_hip_relinearize(fhe_hip_ctx *c, uint64_t *out, const uint64_t *ct3, uint32_t Li, size_t batch, int mem_kind) {
+  TRY(check_ctx(c));
+  if (!out || !ct3) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  TRY(check_li(c, Li, 2));
+  if (batch == 0) return FHE_HIP_OK;
+  const u64 N = c->N;
+  Staged st(c, mem_kind);
+  const u64 *din = nullptr; u64 *dout = nullptr;
+  TRY(st.in(ct3, batch * 3 * Li * N * 8, &din));
+  TRY(st.out(out, batch * 2 * (Li - 1) * N * 8, &dout, false));
+  TRY(ensure_ws(c, 4, batch * 2 * Li * N * 8));
+  u64 *rl = (u64 *)c->ws[4];
+  TRY(dev_relin(c, rl, din, Li, (u32)batch));
+  TRY(dev_rescale_ntt(c, dout, rl, Li, (u32)batch));
+  return st.finish();
+}
+
+int fhe_hip_mul_relin_rescale(fhe_hip_ctx *c, uint64_t *out, const uint64_t *c0, const uint64_t *c1, uint32_t Li, size_t batch, int mem_kind) {
+  TRY(check_ctx(c));
+  if (!out || !c0 || !c1) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  TRY(check_li(c, Li, 2));
+  if (batch == 0) return FHE_HIP_OK;
+  const u64 N = c->N;
+  const size_t ctb = batch * 2 * Li * N * 8;
+  Staged st(c, mem_kind);
+  const u64 *d0 = nullptr, *d1 = nullptr; u64 *dout = nullptr;
+  TRY(st.in(c0, ctb, &d0)); TRY(st.in(c1, ctb, &d1));
+  TRY(st.out(out, batch * 2 * (Li - 1) * N * 8, &dout, false));
+  TRY(dev_mul_relin_rescale(c, dout, d0, d1, Li, (u32)batch));
+  return st.finish();
+}
+
+int fhe_hip_rotate(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind) {
+  TRY(check_ctx(c));
+  if (!ct) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (galois == 0) return FHE_HIP_OK;  // evaluator.cpp:303-304
+  if (!(galois & 1) || galois >= 2 * c->N) FAIL(c, FHE_HIP_ERR_ARG, "galois must be odd and < 2N");
+  TRY(check_li(c, Li, 2));  // Li <= 1: mod_up throws (base_converter.cpp:284-285)
+  if (c->K < 1) FAIL(c, FHE_HIP_ERR_RANGE, "rotation needs special primes");
+  if (batch == 0) return FHE_HIP_OK;
+  Staged st(c, mem_kind);
+  u64 *d = nullptr;
+  TRY(st.out(ct, batch * 2 * Li * c->N * 8, &d, true));
+  TRY(dev_rotate(c, galois, d, Li, (u32)batch));
+  return st.finish();
+}
+
+int fhe_hip_profile_enable(fhe_hip_ctx *c, int on) { TRY(check_ctx(c)); c->prof = on != 0; return FHE_HIP_OK; }
+int fhe_hip_profile_reset(fhe_hip_ctx *c) {
+  TRY(check_ctx(c));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  prof_drain(c);
+  for (auto &e : c->prof_entries) { e.launches = 0; e.total_ms = 0; }
+  return FHE_HIP_OK;
+}
+int fhe_hip_profile_get(fhe_hip_ctx *c, const char **names, uint64_t *launches, double *total_ms, int cap) {
+  if (!c) return FHE_HIP_ERR_ARG;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  prof_drain(c);
+  int n = 0;
+  for (auto &e : c->prof_entries) {
+    if (n < cap) { if (names) names[n] = e.name.c_str(); if (launches) launches[n] = e.launches; if (total_ms) total_ms[n] = e.total_ms; }
+    ++n;
+  }
+  return n;
+}
+
+}  // extern "C"

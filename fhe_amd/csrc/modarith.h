@@ -1,0 +1,97 @@
+// modarith.h — 64-bit modular arithmetic for gfx950 (device side).
+//
+// Replaces the inner bodies of yell::ops::{mulmod, mulmod_shoup, addmod, muladd, barret_reduction}
+// (absent third-party library; usage: reference include/fHE/yell.hpp:14-18, src/base_converter.cpp:227-238,
+// src/evaluator.cpp:636-642).  Everything multiplicative is Montgomery (R = 2^64) with constants stored
+// in Montgomery form, so data never leaves the plain domain: mont(w~, x) = w*x mod p for w~ = w*R mod p.
+// gfx950 has no 64-bit multiplier: products are built from v_mad_u64_u32 (half rate, measured in
+// tools/ubench/mulrate.hip).  A prime with p = 1 (mod 2^32) ("SP" form, the repo's prime table) makes the
+// Montgomery quotient multiplication-free and cuts a modular multiply from 11 to 6 32-bit multiplies.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+struct PrimeC {
+  u64 p;       // modulus, < 2^62
+  u64 twop;    // 2p
+  u64 pinv;    // p^-1 mod 2^64
+  u64 r2;      // 2^128 mod p  (to-Montgomery factor)
+  u64 ninv_m;  // N^-1 mod p in Montgomery form
+  u32 p1;      // p >> 32
+  u32 pad;
+};
+
+__device__ __forceinline__ u64 mad_wide(u32 a, u32 b, u64 c) { return (u64)a * (u64)b + c; }
+
+// (thi:tlo) * 2^-64 mod p, in (0, 2p) provided thi < p.  With thi < c*p the result is < (c+1)*p.
+template <bool SP>
+__device__ __forceinline__ u64 mont_reduce(u64 thi, u64 tlo, const PrimeC &P) {
+  if constexpr (SP) {
+    // p = p1*2^32 + 1  =>  p^-1 = 1 - p1*2^32 (mod 2^64):  m = tlo * p^-1 has m0 = T0, m1 = T1 - lo32(T0*p1)
+    // hi64(m*p) = m1*p1 + ((T0*p1 + m1) >> 32)
+    const u32 T0 = (u32)tlo, T1 = (u32)(tlo >> 32);
+    const u64 v = mad_wide(T0, P.p1, 0);
+    const u32 m1 = T1 - (u32)v;
+    const u64 s = v + m1;
+    const u64 w = mad_wide(m1, P.p1, s >> 32);
+    return thi + P.p - w;
+  } else {
+    const u64 m = tlo * P.pinv;
+    const u64 w = __umul64hi(m, P.p);
+    return thi + P.p - w;
+  }
+}
+
+// a * b * 2^-64 mod p in (0, 2p); a < p (Montgomery-form constant or canonical data), b any 64-bit value.
+template <bool SP>
+__device__ __forceinline__ u64 mont_mul(u64 a, u64 b, const PrimeC &P) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  const u64 t0 = mad_wide(a0, b0, 0);
+  const u64 t1 = mad_wide(a0, b1, t0 >> 32);
+  const u64 t2 = mad_wide(a1, b0, (u64)(u32)t1);
+  const u64 thi = mad_wide(a1, b1, (t1 >> 32) + (t2 >> 32));
+  const u64 tlo = (t2 << 32) | (u64)(u32)t0;
+  return mont_reduce<SP>(thi, tlo, P);
+}
+
+__device__ __forceinline__ u64 csub(u64 x, u64 m) { return x >= m ? x - m : x; }
+
+// exact a*b mod p in [0,p); a < p, b < 2^64 (two Montgomery steps: a*b/R, then * R^2/R)
+template <bool SP>
+__device__ __forceinline__ u64 mulmod_full(u64 a, u64 b, const PrimeC &P) {
+  const u64 t = mont_mul<SP>(a, b, P);
+  return csub(mont_mul<SP>(P.r2, t, P), P.p);
+}
+
+// x -> x*R mod p, canonical
+template <bool SP>
+__device__ __forceinline__ u64 to_mont(u64 x, const PrimeC &P) { return csub(mont_mul<SP>(P.r2, x, P), P.p); }
+
+// 128-bit accumulate helper: (hi:lo) += a*b
+__device__ __forceinline__ void mac128(u64 &hi, u64 &lo, u64 a, u64 b) {
+  const u64 l = a * b;
+  const u64 h = __umul64hi(a, b);
+  lo += l;
+  hi += h + (lo < l ? 1 : 0);
+}
+
+// Harvey lazy Cooley-Tukey butterfly: X, Y in [0,4p) -> [0,4p);  W in Montgomery form
+template <bool SP>
+__device__ __forceinline__ void ct_bfly(u64 &X, u64 &Y, u64 W, const PrimeC &P) {
+  const u64 x = csub(X, P.twop);
+  const u64 t = mont_mul<SP>(W, Y, P);  // (0, 2p)
+  X = x + t;
+  Y = x - t + P.twop;
+}
+
+// lazy Gentleman-Sande butterfly: X, Y in [0,2p) -> [0,2p)
+template <bool SP>
+__device__ __forceinline__ void gs_bfly(u64 &X, u64 &Y, u64 W, const PrimeC &P) {
+  const u64 s = X + Y;
+  const u64 d = X - Y + P.twop;
+  X = csub(s, P.twop);
+  Y = mont_mul<SP>(W, d, P);
+}

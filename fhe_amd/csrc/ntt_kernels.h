@@ -1,0 +1,228 @@
+// ntt_kernels.h — batched negacyclic NTT for gfx950: replaces yell::ntt<N>::forward/backward
+// (absent library; call sites reference src/evaluator.cpp:365,390,668,707, src/base_converter.cpp:224,260).
+//
+// Ordering contract (reference src/yell.cpp:16-21): natural-order coefficients in, evaluations at
+// psi^(2*brv(d)+1) out (bit-reversed), i.e. the merged-twiddle Cooley-Tukey forward / Gentleman-Sande
+// inverse with twiddle table tw[k] = psi^brv(k) (Montgomery form).  Stage s (m = 2^s groups) uses
+// tw[2^s + (element_index >> (logN - s))].
+//
+// Decomposition: N = R x 256.  Forward = column pass (stages 0..logR-1, stride-256 butterflies over an
+// R x CT tile held in LDS) then row pass (stages logR..logN-1 inside contiguous 256-element rows).
+// Inverse = row pass then column pass (+ N^-1).  Inside a pass every thread keeps 16 elements in
+// registers for 4 stages (radix-16), exchanging through LDS once; values stay lazy ([0,4p) forward,
+// [0,2p) inverse) and are made canonical only by the last pass.
+#pragma once
+#include "modarith.h"
+
+struct NttArgs {
+  const u64 *src;       // source limbs
+  u64 *dst;             // destination limbs (may equal src)
+  const u64 *tw;        // [M][N] twiddles (forward or inverse table), Montgomery form
+  const PrimeC *primes; // [M]
+  const u32 *midx;      // modulus map: limb l of a batch entry uses midx[(l / mdiv) % mper]
+  u32 mdiv, mper;
+  u32 smod;             // source limb = l % smod (broadcast of a source limb over several outputs)
+  u32 logN, logR;
+  u64 src_bstride, dst_bstride;  // elements between batch entries
+};
+
+__device__ __forceinline__ u64 canon4(u64 v, const PrimeC &P) { return csub(csub(v, P.twop), P.p); }
+
+template <bool SP, int LK>
+__device__ __forceinline__ void fwd_phase(u64 (&e)[1 << LK], const u64 *__restrict__ tw, u32 base, const PrimeC &P) {
+#pragma unroll
+  for (int q = 0; q < LK; ++q) {
+    const int half = 1 << (LK - 1 - q);
+#pragma unroll
+    for (int kk = 0; kk < (1 << q); ++kk) {
+      const u64 W = tw[(base << q) + kk];
+#pragma unroll
+      for (int j = 0; j < half; ++j) {
+        const int a = kk * 2 * half + j;
+        ct_bfly<SP>(e[a], e[a + half], W, P);
+      }
+    }
+  }
+}
+
+template <bool SP, int LK>
+__device__ __forceinline__ void inv_phase(u64 (&e)[1 << LK], const u64 *__restrict__ tw, u32 base, const PrimeC &P) {
+#pragma unroll
+  for (int q = LK - 1; q >= 0; --q) {
+    const int half = 1 << (LK - 1 - q);
+#pragma unroll
+    for (int kk = 0; kk < (1 << q); ++kk) {
+      const u64 W = tw[(base << q) + kk];
+#pragma unroll
+      for (int j = 0; j < half; ++j) {
+        const int a = kk * 2 * half + j;
+        gs_bfly<SP>(e[a], e[a + half], W, P);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row pass: 8 stages inside contiguous 256-element rows.  Block = 16*ROWS threads, ROWS rows of one limb.
+// LDS image per row: 16 chunks of 16 elements, chunk stride 18 (conflict-free ds_read_b128).
+// ---------------------------------------------------------------------------------------------
+constexpr int ROW_LDS = 16 * 18;
+
+template <bool SP, bool INVERSE>
+__global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
+  __shared__ __attribute__((aligned(16))) u64 lds[16 * ROW_LDS];
+  const u32 tid = threadIdx.x, rloc = tid >> 4, t = tid & 15;
+  const u32 rows_per_wg = blockDim.x >> 4;
+  const u32 row = blockIdx.x * rows_per_wg + rloc;
+  const u32 l = blockIdx.y, b = blockIdx.z;
+  const u32 m = a.midx[(l / a.mdiv) % a.mper];
+  const PrimeC P = a.primes[m];
+  const u64 N = 1ull << a.logN;
+  const u64 *__restrict__ tw = a.tw + (u64)m * N;
+  const u64 *s = a.src + (u64)b * a.src_bstride + (u64)(l % a.smod) * N + (u64)row * 256;
+  u64 *d = a.dst + (u64)b * a.dst_bstride + (u64)l * N + (u64)row * 256;
+  u64 *L = lds + rloc * ROW_LDS;
+  const u32 baseA = (1u << a.logR) + row;
+  u64 e[16];
+  if constexpr (!INVERSE) {
+    // phase A: spans 128..16, thread holds {t + 16k}
+#pragma unroll
+    for (int k = 0; k < 16; ++k) e[k] = s[t + 16 * k];
+    fwd_phase<SP, 4>(e, tw, baseA, P);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) L[k * 18 + t] = e[k];
+    __syncthreads();
+    // phase B: spans 8..1, thread holds {16t + k}
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+      const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[t * 18 + k]);
+      e[k] = v.x; e[k + 1] = v.y;
+    }
+    fwd_phase<SP, 4>(e, tw, (baseA << 4) + t, P);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) e[k] = canon4(e[k], P);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) *reinterpret_cast<ulonglong2 *>(&L[t * 18 + k]) = make_ulonglong2(e[k], e[k + 1]);
+    __syncthreads();
+    // coalesced 16-byte stores: instruction i covers elements [32i, 32i+32) of the row
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[(2 * i + (t >> 3)) * 18 + ((2 * t) & 15)]);
+      *reinterpret_cast<ulonglong2 *>(&d[32 * i + 2 * t]) = v;
+    }
+  } else {
+    // inverse: spans 1..8 first (thread holds {16t + k}), then spans 16..128 ({t + 16k}); output lazy [0,2p)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&s[32 * i + 2 * t]);
+      *reinterpret_cast<ulonglong2 *>(&L[(2 * i + (t >> 3)) * 18 + ((2 * t) & 15)]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+      const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[t * 18 + k]);
+      e[k] = v.x; e[k + 1] = v.y;
+    }
+    inv_phase<SP, 4>(e, tw, (baseA << 4) + t, P);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) *reinterpret_cast<ulonglong2 *>(&L[t * 18 + k]) = make_ulonglong2(e[k], e[k + 1]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) e[k] = L[k * 18 + t];
+    inv_phase<SP, 4>(e, tw, baseA, P);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) d[t + 16 * k] = e[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column pass: LOGR stages over rows (stride 256 elements).  Tile = R rows x CT columns in LDS
+// ([R][CT+1]); threads = R*CT/16.  Two register phases: LA = max(LOGR-4,0) stages on rows
+// {g + (R>>LA) k}, then LB = min(LOGR,4) stages on rows {(u << LB) + k}; inverse runs them mirrored
+// and multiplies by N^-1 (output canonical).
+// ---------------------------------------------------------------------------------------------
+template <int LOGR> struct ColCfg {
+  static constexpr int R = 1 << LOGR;
+  static constexpr int LA = LOGR > 4 ? LOGR - 4 : 0;
+  static constexpr int LB = LOGR > 4 ? 4 : LOGR;
+  static constexpr int CT = R >= 64 ? 16 : 16 * (64 / R);
+  static constexpr int CS = CT + 1;
+  static constexpr int THREADS = R * CT / 16;
+};
+
+template <bool SP, bool INVERSE, int LOGR>
+__global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs a) {
+  using Cfg = ColCfg<LOGR>;
+  constexpr int R = Cfg::R, LA = Cfg::LA, LB = Cfg::LB, CT = Cfg::CT, CS = Cfg::CS, T = Cfg::THREADS;
+  __shared__ u64 lds[R * CS];
+  const u32 tid = threadIdx.x;
+  const u32 l = blockIdx.y, b = blockIdx.z;
+  const u32 m = a.midx[(l / a.mdiv) % a.mper];
+  const PrimeC P = a.primes[m];
+  const u64 N = 1ull << a.logN;
+  const u64 *__restrict__ tw = a.tw + (u64)m * N;
+  const u32 col0 = blockIdx.x * CT;
+  const u64 *s = a.src + (u64)b * a.src_bstride + (u64)(l % a.smod) * N + col0;
+  u64 *d = a.dst + (u64)b * a.dst_bstride + (u64)l * N + col0;
+
+  if constexpr (!INVERSE) {
+    if constexpr (LA > 0) {
+      constexpr int G = R >> LA;  // row groups in phase A
+#pragma unroll
+      for (int rep = 0; rep < (16 >> LA); ++rep) {
+        const u32 slot = tid + rep * T, g = slot / CT, c = slot % CT;
+        u64 e[1 << LA];
+#pragma unroll
+        for (int k = 0; k < (1 << LA); ++k) e[k] = s[(u64)(g + G * k) * 256 + c];
+        fwd_phase<SP, LA>(e, tw, 1u, P);
+#pragma unroll
+        for (int k = 0; k < (1 << LA); ++k) lds[(g + G * k) * CS + c] = e[k];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int rep = 0; rep < (16 >> LB); ++rep) {
+      const u32 slot = tid + rep * T, u = slot / CT, c = slot % CT;
+      u64 e[1 << LB];
+#pragma unroll
+      for (int k = 0; k < (1 << LB); ++k) {
+        const u32 row = (u << LB) + k;
+        e[k] = (LA > 0) ? lds[row * CS + c] : s[(u64)row * 256 + c];
+      }
+      fwd_phase<SP, LB>(e, tw, (1u << LA) + u, P);
+#pragma unroll
+      for (int k = 0; k < (1 << LB); ++k) d[(u64)((u << LB) + k) * 256 + c] = e[k];  // lazy [0,4p)
+    }
+  } else {
+#pragma unroll
+    for (int rep = 0; rep < (16 >> LB); ++rep) {
+      const u32 slot = tid + rep * T, u = slot / CT, c = slot % CT;
+      u64 e[1 << LB];
+#pragma unroll
+      for (int k = 0; k < (1 << LB); ++k) e[k] = s[(u64)((u << LB) + k) * 256 + c];
+      inv_phase<SP, LB>(e, tw, (1u << LA) + u, P);
+#pragma unroll
+      for (int k = 0; k < (1 << LB); ++k) {
+        const u32 row = (u << LB) + k;
+        if constexpr (LA > 0) lds[row * CS + c] = e[k];
+        else d[(u64)row * 256 + c] = csub(mont_mul<SP>(P.ninv_m, e[k], P), P.p);
+      }
+    }
+    if constexpr (LA > 0) {
+      constexpr int G = R >> LA;
+      __syncthreads();
+#pragma unroll
+      for (int rep = 0; rep < (16 >> LA); ++rep) {
+        const u32 slot = tid + rep * T, g = slot / CT, c = slot % CT;
+        u64 e[1 << LA];
+#pragma unroll
+        for (int k = 0; k < (1 << LA); ++k) e[k] = lds[(g + G * k) * CS + c];
+        inv_phase<SP, LA>(e, tw, 1u, P);
+#pragma unroll
+        for (int k = 0; k < (1 << LA); ++k) d[(u64)(g + G * k) * 256 + c] = csub(mont_mul<SP>(P.ninv_m, e[k], P), P.p);
+      }
+    }
+  }
+}

@@ -1,0 +1,204 @@
+// pointwise_kernels.h — coalesced limb-major pointwise / base-conversion kernels for gfx950.
+// Integer mat-vec and elementwise work: HBM-bound, no MFMA.  Every thread owns two adjacent
+// coefficients (one 16-byte access per operand); grid = (N/512, limb, batch entry).
+// Reference loops replaced are cited per kernel (paths relative to the reference root).
+#pragma once
+#include "modarith.h"
+
+#define PW_THREADS 256
+
+__device__ __forceinline__ ulonglong2 ld2(const u64 *p) { return *reinterpret_cast<const ulonglong2 *>(p); }
+__device__ __forceinline__ void st2(u64 *p, u64 x, u64 y) { *reinterpret_cast<ulonglong2 *>(p) = make_ulonglong2(x, y); }
+__device__ __forceinline__ u64 addmod_c(u64 a, u64 b, u64 p) { return csub(a + b, p); }
+
+// Mul::cross_mult (src/evaluator.cpp:621-647): c0,c1 = [b][2][Li][N] -> out3 = [b][3][Li][N]
+template <bool SP>
+__global__ __launch_bounds__(PW_THREADS) void cross_mult_kernel(u64 *out3, const u64 *c0, const u64 *c1, const PrimeC *primes,
+                                                                u32 Li, u64 N) {
+  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
+  const u32 l = blockIdx.y, b = blockIdx.z;
+  const PrimeC P = primes[l];
+  const u64 in = ((u64)b * 2 * Li + l) * N + d, half = (u64)Li * N;
+  const ulonglong2 b0 = ld2(c0 + in), a0 = ld2(c0 + in + half), b1 = ld2(c1 + in), a1 = ld2(c1 + in + half);
+  u64 r0[2], r1[2], r2[2];
+  const u64 vb0[2] = {b0.x, b0.y}, va0[2] = {a0.x, a0.y}, vb1[2] = {b1.x, b1.y}, va1[2] = {a1.x, a1.y};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    r0[i] = mulmod_full<SP>(vb0[i], vb1[i], P);
+    r2[i] = mulmod_full<SP>(va0[i], va1[i], P);
+    u64 hi = 0, lo = 0;  // b0*a1 + b1*a0 < 2p^2: one lazy 128-bit sum, one reduction (evaluator.cpp:636-642)
+    mac128(hi, lo, vb0[i], va1[i]);
+    mac128(hi, lo, vb1[i], va0[i]);
+    const u64 t = mont_reduce<SP>(hi, lo, P);
+    r1[i] = csub(mont_mul<SP>(P.r2, t, P), P.p);
+  }
+  const u64 o = ((u64)b * 3 * Li + l) * N + d;
+  st2(out3 + o, r0[0], r0[1]);
+  st2(out3 + o + half, r1[0], r1[1]);
+  st2(out3 + o + 2 * half, r2[0], r2[1]);
+}
+
+// key-MAC of Mul::reLinearize (src/evaluator.cpp:666-691): out[h][i] = (sum_j key_h[j][i] * t[i][j] + ct[h][i]) mod q_i
+// t = [b][Li(i)][Li(j)][N]; keys in Montgomery form [L][L][N]; ct3 = [b][3][Li][N]; out = [b][2][Li][N]
+template <bool SP>
+__global__ __launch_bounds__(PW_THREADS) void relin_mac_kernel(u64 *out, const u64 *t, const u64 *ct3, const u64 *beta_m,
+                                                               const u64 *alpha_m, const PrimeC *primes, u32 Li, u32 L, u64 N) {
+  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
+  const u32 i = blockIdx.y, b = blockIdx.z;
+  const PrimeC P = primes[i];
+  const u64 *tp = t + (((u64)b * Li + i) * Li) * N + d;
+  u64 acc0[2] = {0, 0}, acc1[2] = {0, 0};
+  for (u32 j = 0; j < Li; ++j) {
+    const ulonglong2 x = ld2(tp + (u64)j * N);
+    const ulonglong2 kb = ld2(beta_m + ((u64)j * L + i) * N + d), ka = ld2(alpha_m + ((u64)j * L + i) * N + d);
+    acc0[0] = csub(acc0[0] + mont_mul<SP>(kb.x, x.x, P), P.twop);
+    acc0[1] = csub(acc0[1] + mont_mul<SP>(kb.y, x.y, P), P.twop);
+    acc1[0] = csub(acc1[0] + mont_mul<SP>(ka.x, x.x, P), P.twop);
+    acc1[1] = csub(acc1[1] + mont_mul<SP>(ka.y, x.y, P), P.twop);
+  }
+  const u64 ci = ((u64)b * 3 * Li + i) * N + d, half = (u64)Li * N;
+  const ulonglong2 d0 = ld2(ct3 + ci), d1 = ld2(ct3 + ci + half);
+  const u64 o = ((u64)b * 2 * Li + i) * N + d;
+  st2(out + o, addmod_c(csub(acc0[0], P.p), d0.x, P.p), addmod_c(csub(acc0[1], P.p), d0.y, P.p));
+  st2(out + o + half, addmod_c(csub(acc1[0], P.p), d1.x, P.p), addmod_c(csub(acc1[1], P.p), d1.y, P.p));
+}
+
+// BaseConverter::rescale inner loop (src/base_converter.cpp:264-271): out_j = (head_j + q_j - tail_j) * q_last^-1 mod q_j
+// head = [e][n][N] (limbs j < n-1 used), tail = [e][n-1][N], out = [e][n-1][N]; qinv_m = row (n-1) of the
+// (P[a]^-1 mod P[j]) table in Montgomery form.
+template <bool SP>
+__global__ __launch_bounds__(PW_THREADS) void rescale_kernel(u64 *out, const u64 *head, const u64 *tail, const u64 *qinv_m,
+                                                             const PrimeC *primes, u32 n, u64 N) {
+  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
+  const u32 j = blockIdx.y, e = blockIdx.z;
+  const PrimeC P = primes[j];
+  const u64 qi = qinv_m[j];
+  const ulonglong2 h = ld2(head + ((u64)e * n + j) * N + d), tl = ld2(tail + ((u64)e * (n - 1) + j) * N + d);
+  st2(out + ((u64)e * (n - 1) + j) * N + d, csub(mont_mul<SP>(qi, h.x + P.p - tl.x, P), P.p),
+      csub(mont_mul<SP>(qi, h.y + P.p - tl.y, P), P.p));
+}
+
+// internal::do_approximated_basis_conversion (src/base_converter.cpp:313-349), all targets of one
+// conversion: out[t][d] = ( sum_k [x_k[d] * inv_k]_{src_k} * hat[t][k] ) mod tgt_t   (uncorrected).
+// src = [e][src_limbs][N] (limbs src_off .. src_off+nsrc), out = [e][out_limbs][N] (limbs out_off + t).
+struct BconvArgs {
+  u64 *out; const u64 *src;
+  const u64 *inv_m;   // [nsrc]  Montgomery form w.r.t. the source prime
+  const u64 *hat_m;   // [ntgt][hat_stride]  Montgomery form w.r.t. the target prime
+  const PrimeC *primes;
+  u32 nsrc, src_first, src_limbs, src_off;
+  u32 tgt_first, out_limbs, out_off, hat_stride;
+  u64 N;
+};
+template <bool SP>
+__global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
+  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
+  const u32 t = blockIdx.y, e = blockIdx.z;
+  const PrimeC PT = a.primes[a.tgt_first + t];
+  const u64 *sp = a.src + ((u64)e * a.src_limbs + a.src_off) * a.N + d;
+  const u64 *hat = a.hat_m + (u64)t * a.hat_stride;
+  u64 acc[2] = {0, 0};
+  for (u32 k = 0; k < a.nsrc; ++k) {
+    const PrimeC PS = a.primes[a.src_first + k];
+    const ulonglong2 x = ld2(sp + (u64)k * a.N);
+    const u64 inv = a.inv_m[k], h = hat[k];
+    const u64 t0 = csub(mont_mul<SP>(inv, x.x, PS), PS.p);  // canonical residue mod the source prime
+    const u64 t1 = csub(mont_mul<SP>(inv, x.y, PS), PS.p);
+    acc[0] = csub(acc[0] + mont_mul<SP>(h, t0, PT), PT.twop);
+    acc[1] = csub(acc[1] + mont_mul<SP>(h, t1, PT), PT.twop);
+  }
+  st2(a.out + ((u64)e * a.out_limbs + a.out_off + t) * a.N + d, csub(acc[0], PT.p), csub(acc[1], PT.p));
+}
+
+// tail of approximated_mod_down (src/base_converter.cpp:227-240): out_j = (src_j + conv_j) * P^-1 mod q_j,
+// optionally followed by "+ addend_j" (evaluator.cpp:398).  src = [e][src_limbs][N], conv/out/addend = [e][L0][N].
+template <bool SP>
+__global__ __launch_bounds__(PW_THREADS) void moddown_final_kernel(u64 *out, const u64 *src, const u64 *conv, const u64 *addend,
+                                                                   const u64 *pinv_m, const PrimeC *primes, u32 L0, u32 src_limbs,
+                                                                   u64 N) {
+  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
+  const u32 j = blockIdx.y, e = blockIdx.z;
+  const PrimeC P = primes[j];
+  const u64 pi = pinv_m[j];
+  const u64 o = ((u64)e * L0 + j) * N + d;
+  const ulonglong2 s = ld2(src + ((u64)e * src_limbs + j) * N + d), c = ld2(conv + o);
+  u64 r0 = csub(mont_mul<SP>(pi, s.x + c.x, P), P.p), r1 = csub(mont_mul<SP>(pi, s.y + c.y, P), P.p);
+  if (addend) {
+    const ulonglong2 ad = ld2(addend + o);
+    r0 = addmod_c(r0, ad.x, P.p); r1 = addmod_c(r1, ad.y, P.p);
+  }
+  st2(out + o, r0, r1);
+}
+
+// key multiply of apply_rotation_key (src/evaluator.cpp:373-384): e0 = ext * beta[idx], e1 = ext * alpha[idx],
+// idx = midx[cm] (cm < Li ? cm : L + cm - Li).  ext/e0/e1 = [b][nl][N]; keys [L+K][N] Montgomery form.
+template <bool SP>
+__global__ __launch_bounds__(PW_THREADS) void rot_keymul_kernel(u64 *e0, u64 *e1, const u64 *ext, const u64 *beta_m,
+                                                                const u64 *alpha_m, const PrimeC *primes, const u32 *midx, u32 nl,
+                                                                u64 N) {
+  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
+  const u32 cm = blockIdx.y, b = blockIdx.z;
+  const u32 m = midx[cm];
+  const PrimeC P = primes[m];
+  const u64 o = ((u64)b * nl + cm) * N + d;
+  const ulonglong2 x = ld2(ext + o), kb = ld2(beta_m + (u64)m * N + d), ka = ld2(alpha_m + (u64)m * N + d);
+  st2(e0 + o, csub(mont_mul<SP>(kb.x, x.x, P), P.p), csub(mont_mul<SP>(kb.y, x.y, P), P.p));
+  st2(e1 + o, csub(mont_mul<SP>(ka.x, x.x, P), P.p), csub(mont_mul<SP>(ka.y, x.y, P), P.p));
+}
+
+// fHE::apply_galois (src/yell.cpp:14-24) as a gather through a per-galois index table; out-of-place.
+__global__ __launch_bounds__(PW_THREADS) void galois_gather_kernel(u64 *dst, const u64 *src, const u32 *perm, u64 N) {
+  const u64 d = (u64)blockIdx.x * PW_THREADS + threadIdx.x;
+  const u64 o = ((u64)blockIdx.z * gridDim.y + blockIdx.y) * N;
+  dst[o + d] = src[o + perm[d]];
+}
+__global__ void galois_perm_kernel(u32 *perm, u32 logN, u64 galois) {
+  const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 N = 1u << logN;
+  if (d >= N) return;
+  const u32 r = __brev(d) >> (32 - logN);
+  const u64 raw = (galois * (2ull * r + 1)) & (2ull * N - 1);
+  perm[d] = __brev((u32)((raw - 1) >> 1)) >> (32 - logN);
+}
+// fHE::apply_galois_non_ntt (src/yell.cpp:41-52): scatter with sign flip; limb k uses modulus k; out-of-place.
+__global__ __launch_bounds__(PW_THREADS) void galois_coeff_kernel(u64 *dst, const u64 *src, const PrimeC *primes, u32 logN,
+                                                                  u64 galois) {
+  const u64 N = 1ull << logN;
+  const u64 d = (u64)blockIdx.x * PW_THREADS + threadIdx.x;
+  const u32 cm = blockIdx.y;
+  const u64 o = ((u64)blockIdx.z * gridDim.y + cm) * N;
+  const u64 raw = d * galois;
+  const u64 t = src[o + d];
+  const u64 p = primes[cm].p;
+  dst[o + (raw & (N - 1))] = ((raw >> logN) & 1) ? (t > 0 ? p - t : 0) : t;
+}
+
+// poly operator+= (src/evaluator.cpp:284-285): rop, op = [e][nl][N], limb k uses modulus k
+__global__ __launch_bounds__(PW_THREADS) void add_kernel(u64 *rop, const u64 *op, const PrimeC *primes, u64 N) {
+  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
+  const u64 p = primes[blockIdx.y].p;
+  const u64 o = ((u64)blockIdx.z * gridDim.y + blockIdx.y) * N + d;
+  const ulonglong2 a = ld2(rop + o), b = ld2(op + o);
+  st2(rop + o, addmod_c(a.x, b.x, p), addmod_c(a.y, b.y, p));
+}
+
+// Evaluator::multiply_plain (src/evaluator.cpp:97-106): ct = [b][2][nl][N] *= pt [nl][N]
+template <bool SP>
+__global__ __launch_bounds__(PW_THREADS) void mul_plain_kernel(u64 *ct, const u64 *pt, const PrimeC *primes, u32 nl, u64 N) {
+  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
+  const u32 l = blockIdx.y % nl;
+  const PrimeC P = primes[l];
+  const u64 o = ((u64)blockIdx.z * gridDim.y + blockIdx.y) * N + d;
+  const ulonglong2 x = ld2(ct + o), y = ld2(pt + (u64)l * N + d);
+  st2(ct + o, mulmod_full<SP>(y.x, x.x, P), mulmod_full<SP>(y.y, x.y, P));
+}
+
+// key upload: x -> x * 2^64 mod p in place; limb l uses midx[l % mper]
+template <bool SP>
+__global__ __launch_bounds__(PW_THREADS) void to_mont_kernel(u64 *x, const PrimeC *primes, const u32 *midx, u32 mper, u64 N) {
+  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
+  const PrimeC P = primes[midx[blockIdx.y % mper]];
+  const u64 o = (u64)blockIdx.y * N + d;
+  const ulonglong2 v = ld2(x + o);
+  st2(x + o, to_mont<SP>(v.x, P), to_mont<SP>(v.y, P));
+}

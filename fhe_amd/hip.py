@@ -1,0 +1,238 @@
+"""ctypes binding of libfhe_hip.so (C-ABI: include/fhe_hip.h).
+
+Buffers are either torch CUDA tensors (dtype int64, bit pattern = uint64 limbs; device pointers are
+passed straight through, no copies) or C-contiguous numpy uint64 arrays (host pointers, staged by
+the library).  PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libfhe_hip.so")
+
+MEM_DEVICE, MEM_HOST = 0, 1
+
+_lib = None
+
+
+class FheHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("fhe_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load_library():
+    """Load libfhe_hip.so; raises if it has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            "%s not found: build it with `make -C fhe_amd/csrc` (or python -c 'import __graft_entry__ as g; g.build()')" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, u32, u64, i, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_size_t
+    sig = {
+        "fhe_hip_ctx_create": (i, [C.POINTER(vp), u32, u32, u32, vp, vp, i]),
+        "fhe_hip_ctx_destroy": (None, [vp]),
+        "fhe_hip_last_error": (C.c_char_p, [vp]),
+        "fhe_hip_set_stream": (i, [vp, vp]),
+        "fhe_hip_sync": (i, [vp]),
+        "fhe_hip_ntt_forward": (i, [vp, vp, vp, sz, i]),
+        "fhe_hip_ntt_backward": (i, [vp, vp, vp, sz, i]),
+        "fhe_hip_apply_galois": (i, [vp, vp, u32, u64, sz, i]),
+        "fhe_hip_apply_galois_non_ntt": (i, [vp, vp, u32, u64, sz, i]),
+        "fhe_hip_mod_up": (i, [vp, vp, vp, u32, sz, i]),
+        "fhe_hip_mod_down": (i, [vp, vp, vp, u32, sz, i]),
+        "fhe_hip_rescale": (i, [vp, vp, vp, u32, sz, i]),
+        "fhe_hip_load_mult_key": (i, [vp, vp, vp, i]),
+        "fhe_hip_load_rot_key": (i, [vp, u64, vp, vp, i]),
+        "fhe_hip_add": (i, [vp, vp, vp, u32, sz, i]),
+        "fhe_hip_multiply_plain": (i, [vp, vp, vp, u32, sz, i]),
+        "fhe_hip_cross_mult": (i, [vp, vp, vp, vp, u32, sz, i]),
+        "fhe_hip_relin_only": (i, [vp, vp, vp, u32, sz, i]),
+        "fhe_hip_relinearize": (i, [vp, vp, vp, u32, sz, i]),
+        "fhe_hip_mul_relin_rescale": (i, [vp, vp, vp, vp, u32, sz, i]),
+        "fhe_hip_rotate": (i, [vp, u64, vp, u32, sz, i]),
+        "fhe_hip_profile_enable": (i, [vp, i]),
+        "fhe_hip_profile_reset": (i, [vp]),
+        "fhe_hip_profile_get": (i, [vp, C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double), i]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "fhe_hip_ctx_create", "fhe_hip_ctx_destroy", "fhe_hip_last_error", "fhe_hip_set_stream", "fhe_hip_sync",
+    "fhe_hip_ntt_forward", "fhe_hip_ntt_backward", "fhe_hip_apply_galois", "fhe_hip_apply_galois_non_ntt",
+    "fhe_hip_mod_up", "fhe_hip_mod_down", "fhe_hip_rescale", "fhe_hip_load_mult_key", "fhe_hip_load_rot_key",
+    "fhe_hip_add", "fhe_hip_multiply_plain", "fhe_hip_cross_mult", "fhe_hip_relin_only", "fhe_hip_relinearize",
+    "fhe_hip_mul_relin_rescale", "fhe_hip_rotate", "fhe_hip_profile_enable", "fhe_hip_profile_reset",
+    "fhe_hip_profile_get",
+]
+
+
+def _buf(x):
+    """-> (pointer, mem_kind, keepalive) for a torch CUDA int64 tensor or a numpy uint64 array."""
+    if isinstance(x, np.ndarray):
+        if x.dtype != np.uint64 or not x.flags["C_CONTIGUOUS"]:
+            raise TypeError("host buffers must be C-contiguous numpy uint64 arrays")
+        return x.ctypes.data, MEM_HOST
+    import torch
+    if isinstance(x, torch.Tensor):
+        if not x.is_cuda or x.dtype != torch.int64 or not x.is_contiguous():
+            raise TypeError("device buffers must be contiguous CUDA int64 tensors")
+        return x.data_ptr(), MEM_DEVICE
+    raise TypeError("unsupported buffer type %r" % type(x))
+
+
+def _same_kind(*bufs):
+    ptrs, kinds = zip(*[_buf(b) for b in bufs])
+    if len(set(kinds)) != 1:
+        raise TypeError("all buffers of one call must live on the same side (all host or all device)")
+    return ptrs, kinds[0]
+
+
+class HipContext:
+    """fHE::context made runtime (reference include/fHE/context.hpp:6-25): N = 2**logN, L normal and
+    K special primes; owns the device tables, keys and workspaces of one GPU."""
+
+    def __init__(self, logN, L, K, primes, psi, device=0):
+        self.lib = load_library()
+        self.logN, self.L, self.K, self.N = logN, L, K, 1 << logN
+        pr = np.ascontiguousarray(primes, np.uint64)
+        ps = np.ascontiguousarray(psi, np.uint64)
+        if pr.shape != (L + K,) or ps.shape != (L + K,):
+            raise ValueError("need L+K primes and roots")
+        h = C.c_void_p()
+        rc = self.lib.fhe_hip_ctx_create(C.byref(h), logN, L, K, pr.ctypes.data, ps.ctypes.data, device)
+        if rc:
+            raise FheHipError(rc, self.lib.fhe_hip_last_error(None).decode())
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fhe_hip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise FheHipError(rc, self.lib.fhe_hip_last_error(self.h).decode())
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.fhe_hip_set_stream(self.h, stream_ptr))
+
+    def sync(self):
+        self._chk(self.lib.fhe_hip_sync(self.h))
+
+    # ---- NTT --------------------------------------------------------------------------------
+    def ntt_forward(self, limbs, moduli_idx):
+        idx = np.ascontiguousarray(moduli_idx, np.uint32)
+        (p,), kind = _same_kind(limbs)
+        self._chk(self.lib.fhe_hip_ntt_forward(self.h, p, idx.ctypes.data, idx.size, kind))
+        return limbs
+
+    def ntt_backward(self, limbs, moduli_idx):
+        idx = np.ascontiguousarray(moduli_idx, np.uint32)
+        (p,), kind = _same_kind(limbs)
+        self._chk(self.lib.fhe_hip_ntt_backward(self.h, p, idx.ctypes.data, idx.size, kind))
+        return limbs
+
+    # ---- automorphisms ----------------------------------------------------------------------
+    def apply_galois(self, polys, nlimbs, galois, batch=1):
+        (p,), kind = _same_kind(polys)
+        self._chk(self.lib.fhe_hip_apply_galois(self.h, p, nlimbs, galois, batch, kind))
+        return polys
+
+    def apply_galois_non_ntt(self, polys, nlimbs, galois, batch=1):
+        (p,), kind = _same_kind(polys)
+        self._chk(self.lib.fhe_hip_apply_galois_non_ntt(self.h, p, nlimbs, galois, batch, kind))
+        return polys
+
+    # ---- base converter ---------------------------------------------------------------------
+    def mod_up(self, rop, op, Li, batch=1):
+        (r, o), kind = _same_kind(rop, op)
+        self._chk(self.lib.fhe_hip_mod_up(self.h, r, o, Li, batch, kind))
+        return rop
+
+    def mod_down(self, rop, op, L0, batch=1):
+        (r, o), kind = _same_kind(rop, op)
+        self._chk(self.lib.fhe_hip_mod_down(self.h, r, o, L0, batch, kind))
+        return rop
+
+    def rescale(self, rop, op, n, batch=1):
+        (r, o), kind = _same_kind(rop, op)
+        self._chk(self.lib.fhe_hip_rescale(self.h, r, o, n, batch, kind))
+        return rop
+
+    # ---- keys -------------------------------------------------------------------------------
+    def load_mult_key(self, beta, alpha):
+        (b, a), kind = _same_kind(beta, alpha)
+        self._chk(self.lib.fhe_hip_load_mult_key(self.h, b, a, kind))
+
+    def load_rot_key(self, galois, beta, alpha):
+        (b, a), kind = _same_kind(beta, alpha)
+        self._chk(self.lib.fhe_hip_load_rot_key(self.h, galois, b, a, kind))
+
+    # ---- evaluator --------------------------------------------------------------------------
+    def add(self, rop, op, nlimbs, batch=1):
+        (r, o), kind = _same_kind(rop, op)
+        self._chk(self.lib.fhe_hip_add(self.h, r, o, nlimbs, batch, kind))
+        return rop
+
+    def multiply_plain(self, ct, pt, nlimbs, batch=1):
+        (c, p), kind = _same_kind(ct, pt)
+        self._chk(self.lib.fhe_hip_multiply_plain(self.h, c, p, nlimbs, batch, kind))
+        return ct
+
+    def cross_mult(self, out3, c0, c1, Li, batch=1):
+        (o, a, b), kind = _same_kind(out3, c0, c1)
+        self._chk(self.lib.fhe_hip_cross_mult(self.h, o, a, b, Li, batch, kind))
+        return out3
+
+    def relin_only(self, out, ct3, Li, batch=1):
+        (o, a), kind = _same_kind(out, ct3)
+        self._chk(self.lib.fhe_hip_relin_only(self.h, o, a, Li, batch, kind))
+        return out
+
+    def relinearize(self, out, ct3, Li, batch=1):
+        (o, a), kind = _same_kind(out, ct3)
+        self._chk(self.lib.fhe_hip_relinearize(self.h, o, a, Li, batch, kind))
+        return out
+
+    def mul_relin_rescale(self, out, c0, c1, Li, batch=1):
+        (o, a, b), kind = _same_kind(out, c0, c1)
+        self._chk(self.lib.fhe_hip_mul_relin_rescale(self.h, o, a, b, Li, batch, kind))
+        return out
+
+    def rotate(self, galois, ct, Li, batch=1):
+        (c,), kind = _same_kind(ct)
+        self._chk(self.lib.fhe_hip_rotate(self.h, galois, c, Li, batch, kind))
+        return ct
+
+    # ---- measurement ------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._chk(self.lib.fhe_hip_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self.lib.fhe_hip_profile_reset(self.h))
+
+    def profile_get(self):
+        cap = 64
+        names = (C.c_char_p * cap)()
+        launches = (C.c_uint64 * cap)()
+        ms = (C.c_double * cap)()
+        n = self.lib.fhe_hip_profile_get(self.h, names, launches, ms, cap)
+        if n < 0:
+            self._chk(n)
+        return {names[k].decode(): (int(launches[k]), float(ms[k])) for k in range(min(n, cap))}

@@ -1,0 +1,112 @@
+/*
+ * fhe_hip.h — C-ABI of the MI355X (gfx950) backend for fHE's RNS-CKKS polynomial hot path.
+ *
+ * The reference (fionser/fHE) has no plugin/FFI interface; its seams are the pimpl classes
+ * fHE::Evaluator (include/fHE/evaluator.hpp:13-15, Impl src/evaluator.cpp:12-68) and
+ * fHE::BaseConverter (include/fHE/base_converter.hpp:5-9, Impl src/base_converter.cpp:29-78) and the
+ * raw-pointer calls yell::ntt<N>::forward/backward(T*, size_t moduli_idx).  Each entry point below
+ * cites the reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; 0 = OK, negative = error (fhe_hip_last_error()).
+ *   - limb word = uint64_t, little endian; polynomial = limb-major [nlimbs][N] contiguous
+ *     (yell::poly layout, src/base_converter.cpp:199); ciphertext batch = [ct][half][limb][N] with
+ *     half 0 = bx, half 1 = ax (include/fHE/cipher.hpp:9-10).
+ *   - moduli are addressed by GLOBAL index into the context's prime table: normal primes 0..L-1,
+ *     special primes L..L+K-1 (include/fHE/context.hpp:16-19).
+ *   - mem_kind: FHE_HIP_MEM_DEVICE pointers are device memory of the context's GPU (no copies);
+ *     FHE_HIP_MEM_HOST pointers are host memory, staged through device buffers by the library.
+ *   - caller owns every buffer; one context per device; a context is not thread-safe; work is
+ *     enqueued on the context's stream (fhe_hip_set_stream) and host-memory calls synchronise.
+ *   - NTT-domain values are canonical residues in [0,p) on output; forward-NTT inputs may be any
+ *     value < 4p (residues of another prime of the table: src/evaluator.cpp:667-668); backward-NTT
+ *     and pointwise inputs must be < 2p.
+ */
+#ifndef FHE_HIP_H
+#define FHE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fhe_hip_ctx fhe_hip_ctx;
+
+enum { FHE_HIP_MEM_DEVICE = 0, FHE_HIP_MEM_HOST = 1 };
+
+enum {
+  FHE_HIP_OK = 0,
+  FHE_HIP_ERR_ARG = -1,      /* null pointer / shape mismatch (reference: return false + std::cerr) */
+  FHE_HIP_ERR_RANGE = -2,    /* limb count out of range (reference: std::invalid_argument) */
+  FHE_HIP_ERR_NOKEY = -3,    /* key not loaded */
+  FHE_HIP_ERR_HIP = -4,      /* HIP runtime error */
+  FHE_HIP_ERR_NODEVICE = -5  /* no usable GPU: the library never falls back to the CPU */
+};
+
+/* fHE::context (include/fHE/context.hpp:6-25) made runtime: N = 2^logN, L normal + K special primes,
+ * primes[L+K] (< 2^62, 2N | p-1) and psi[L+K] (primitive 2N-th roots) as in yell::params::P. */
+int fhe_hip_ctx_create(fhe_hip_ctx **out, uint32_t logN, uint32_t L, uint32_t K, const uint64_t *primes,
+                       const uint64_t *psi, int device);
+void fhe_hip_ctx_destroy(fhe_hip_ctx *ctx);
+const char *fhe_hip_last_error(const fhe_hip_ctx *ctx); /* ctx may be NULL: last create() error */
+int fhe_hip_set_stream(fhe_hip_ctx *ctx, void *hip_stream);
+int fhe_hip_sync(fhe_hip_ctx *ctx);
+
+/* yell::ntt<N>::forward / backward(T* limb, size_t moduli_idx) (call sites src/evaluator.cpp:365,390,
+ * 668,707; src/base_converter.cpp:224,260), batched: limbs = [n_limbs][N] in place, moduli_idx[n_limbs]
+ * is a HOST array.  Natural order in, bit-reversed out at psi^(2*brv(d)+1) (src/yell.cpp:16-21);
+ * backward includes N^-1. */
+int fhe_hip_ntt_forward(fhe_hip_ctx *ctx, uint64_t *limbs, const uint32_t *moduli_idx, size_t n_limbs, int mem_kind);
+int fhe_hip_ntt_backward(fhe_hip_ctx *ctx, uint64_t *limbs, const uint32_t *moduli_idx, size_t n_limbs, int mem_kind);
+
+/* fHE::apply_galois / apply_galois_non_ntt (src/yell.cpp:4-25, 29-53): polys = [batch][nlimbs][N] in
+ * place, limb k of a polynomial uses modulus k. */
+int fhe_hip_apply_galois(fhe_hip_ctx *ctx, uint64_t *polys, uint32_t nlimbs, uint64_t galois, size_t batch, int mem_kind);
+int fhe_hip_apply_galois_non_ntt(fhe_hip_ctx *ctx, uint64_t *polys, uint32_t nlimbs, uint64_t galois, size_t batch, int mem_kind);
+
+/* BaseConverter::approximated_mod_up (src/base_converter.cpp:189-203): op [batch][Li][N] power basis
+ * -> rop [batch][Li+K][N].  Li < 2 -> FHE_HIP_ERR_RANGE (:284-285). */
+int fhe_hip_mod_up(fhe_hip_ctx *ctx, uint64_t *rop, const uint64_t *op, uint32_t Li, size_t batch, int mem_kind);
+/* BaseConverter::approximated_mod_down (:205-242): op [batch][L0+K][N] (normal limbs NTT basis, special
+ * limbs power basis) -> rop [batch][L0][N] NTT basis. */
+int fhe_hip_mod_down(fhe_hip_ctx *ctx, uint64_t *rop, const uint64_t *op, uint32_t L0, size_t batch, int mem_kind);
+/* BaseConverter::rescale (:244-274): op [batch][n][N] (last limb power basis, rest NTT basis) ->
+ * rop [batch][n-1][N] NTT basis; floor-style, no rounding term. */
+int fhe_hip_rescale(fhe_hip_ctx *ctx, uint64_t *rop, const uint64_t *op, uint32_t n, size_t batch, int mem_kind);
+
+/* MultKey (include/fHE/mult_key.hpp:5-38): beta/alpha = [L][L][N] (key j, limb i), NTT basis.
+ * RotKey (include/fHE/rot_key.hpp:9-39): beta/alpha = [L+K][N], NTT basis, selected later by galois.
+ * Keys are copied to (and re-encoded on) the device; the caller's buffers are not retained. */
+int fhe_hip_load_mult_key(fhe_hip_ctx *ctx, const uint64_t *beta, const uint64_t *alpha, int mem_kind);
+int fhe_hip_load_rot_key(fhe_hip_ctx *ctx, uint64_t galois, const uint64_t *beta, const uint64_t *alpha, int mem_kind);
+
+/* Evaluator::add (src/evaluator.cpp:270-297, poly operator+=): rop, op = [batch][nlimbs][N]. */
+int fhe_hip_add(fhe_hip_ctx *ctx, uint64_t *rop, const uint64_t *op, uint32_t nlimbs, size_t batch, int mem_kind);
+/* Evaluator::multiply_plain (:88-111): ct [batch][2][nlimbs][N] *= pt [nlimbs][N] on both halves. */
+int fhe_hip_multiply_plain(fhe_hip_ctx *ctx, uint64_t *ct, const uint64_t *pt, uint32_t nlimbs, size_t batch, int mem_kind);
+/* Evaluator::multiply = Mul::cross_mult (:621-647): c0, c1 = [batch][2][Li][N]; out3 = [batch][3][Li][N]
+ * holding (bx, ax, mul_aux). */
+int fhe_hip_cross_mult(fhe_hip_ctx *ctx, uint64_t *out3, const uint64_t *c0, const uint64_t *c1, uint32_t Li, size_t batch, int mem_kind);
+/* Mul::reLinearize only (:649-693): ct3 = [batch][3][Li][N] -> out = [batch][2][Li][N] (no rescale). */
+int fhe_hip_relin_only(fhe_hip_ctx *ctx, uint64_t *out, const uint64_t *ct3, uint32_t Li, size_t batch, int mem_kind);
+/* Evaluator::relinearize = Impl::relinerize_inplace (:599-619): reLinearize + rescale_ntt;
+ * ct3 = [batch][3][Li][N] -> out = [batch][2][Li-1][N]. */
+int fhe_hip_relinearize(fhe_hip_ctx *ctx, uint64_t *out, const uint64_t *ct3, uint32_t Li, size_t batch, int mem_kind);
+/* Evaluator::multiply_and_relin (:119-126): c0, c1 = [batch][2][Li][N] -> out = [batch][2][Li-1][N]. */
+int fhe_hip_mul_relin_rescale(fhe_hip_ctx *ctx, uint64_t *out, const uint64_t *c0, const uint64_t *c1, uint32_t Li, size_t batch, int mem_kind);
+/* Evaluator::rotate_slots(Cipher*, RotKey const&) (:128-136, 299-311, 343-399): ct = [batch][2][Li][N]
+ * in place with the RotKey loaded for `galois`; galois == 0 is a no-op (:303-304). */
+int fhe_hip_rotate(fhe_hip_ctx *ctx, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind);
+
+/* Measurement support (no reference counterpart): when enabled every kernel launch is bracketed by
+ * HIP events on the context's stream; stats are summed per kernel name. */
+int fhe_hip_profile_enable(fhe_hip_ctx *ctx, int on);
+int fhe_hip_profile_reset(fhe_hip_ctx *ctx);
+/* returns number of kernels; fills up to cap entries (name pointers stay valid for the ctx lifetime) */
+int fhe_hip_profile_get(fhe_hip_ctx *ctx, const char **names, uint64_t *launches, double *total_ms, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

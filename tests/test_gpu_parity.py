@@ -1,0 +1,280 @@
+"""GPU parity: every C-ABI entry point against the CPU oracle on identical primes, keys and inputs.
+Bit-exact (integer work).  Sizes are chosen so the oracle finishes in seconds; full-size cases use
+size-independent properties (round trips, linearity)."""
+import numpy as np
+import pytest
+
+import fhe_amd
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(a.view(np.int64)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+_ctx_cache = {}
+
+
+def ctx_pair(logN, L, K, sp=True):
+    key = (logN, L, K, sp)
+    if key not in _ctx_cache:
+        if sp:
+            pr, ps = orc.gen_primes(logN, L + K)
+        else:
+            pr, ps = generic_primes(logN, L + K)
+        _ctx_cache[key] = (orc.Oracle(logN, L, K, pr, ps), fhe_amd.HipContext(logN, L, K, pr, ps))
+    return _ctx_cache[key]
+
+
+def generic_primes(logN, count):
+    """Primes NOT of the p = 1 (mod 2^32) form: exercises the generic Montgomery path."""
+    pr, ps = [], []
+    step = 1 << (logN + 1)
+    p = (1 << 61) + (1 << 60) + 1
+    p -= (p - 1) % step
+    while len(pr) < count:
+        p -= step
+        if p % (1 << 32) != 1 and orc.lib.orc_is_prime(p):
+            x = 2
+            while pow(x, (p - 1) // 2, p) != p - 1:
+                x += 1
+            pr.append(p)
+            ps.append(pow(x, (p - 1) >> (logN + 1), p))
+    return np.array(pr, np.uint64), np.array(ps, np.uint64)
+
+
+def rand_poly(o, idx, seed, bound=None):
+    rng = np.random.default_rng(seed)
+    return np.stack([rng.integers(0, int(o.primes[i]) if bound is None else bound, o.N, dtype=np.uint64) for i in idx])
+
+
+@pytest.mark.parametrize("logN", [10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("sp", [True, False])
+def test_ntt_forward_backward_bit_exact(logN, sp):
+    o, g = ctx_pair(logN, 3, 2, sp)
+    idx = [0, 1, 2, 3, 4, 2, 0]
+    x = rand_poly(o, idx, logN)
+    want = o.ntt_forward(x.copy(), idx)
+    d = dev(x)
+    g.ntt_forward(d, idx)
+    assert np.array_equal(host(d), want)
+    g.ntt_backward(d, idx)
+    assert np.array_equal(host(d), x)
+    y = rand_poly(o, idx, logN + 100)
+    want_b = o.ntt_backward(y.copy(), idx)
+    d = dev(y)
+    g.ntt_backward(d, idx)
+    assert np.array_equal(host(d), want_b)
+
+
+def test_ntt_accepts_foreign_residues_and_edge_values():
+    o, g = ctx_pair(13, 3, 2)
+    idx = [0, 1, 4]
+    x = rand_poly(o, idx, 5, bound=1 << 62)  # residues of another 62-bit prime: >= p allowed
+    x[0, :4] = [0, 1, int(o.primes[0]) - 1, (1 << 62) - 1]
+    want = o.ntt_forward(x.copy(), idx)
+    d = dev(x)
+    g.ntt_forward(d, idx)
+    assert np.array_equal(host(d), want)
+    z = np.zeros((1, o.N), np.uint64)
+    dz = dev(z)
+    g.ntt_forward(dz, [1])
+    assert not host(dz).any()
+
+
+def test_ntt_host_memory_kind():
+    o, g = ctx_pair(12, 3, 2)
+    idx = [1, 3]
+    x = rand_poly(o, idx, 9)
+    want = o.ntt_forward(x.copy(), idx)
+    h = x.copy()
+    g.ntt_forward(h, idx)  # numpy buffer -> FHE_HIP_MEM_HOST
+    assert np.array_equal(h, want)
+
+
+def test_config2_batched_ntt_properties():
+    """BASELINE config 2 shape (N=2^14, 8 limbs, 1024 polys): round trip + spot parity + linearity."""
+    logN, L = 14, 8
+    o, g = ctx_pair(logN, L, 1)
+    npoly = 1024
+    idx = np.tile(np.arange(L, dtype=np.uint32), npoly)
+    gen = torch.Generator(device="cuda").manual_seed(14)
+    x = torch.randint(0, 1 << 61, (npoly * L, o.N), dtype=torch.int64, device="cuda", generator=gen)
+    y = x.clone()
+    g.ntt_forward(y, idx)
+    for k in (0, 5, 8191):
+        want = o.ntt_forward(host(x[k]).copy().reshape(1, -1), [int(idx[k])])[0]
+        assert np.array_equal(host(y[k]), want)
+    # linearity: NTT(a) + NTT(b) == NTT(a + b) mod p on one limb pair
+    p0 = int(o.primes[0])
+    a, b = host(x[0]).astype(object), host(x[8]).astype(object)
+    s = np.array([(int(u) + int(v)) % p0 for u, v in zip(a, b)], dtype=np.uint64).reshape(1, -1)
+    ds = dev(s)
+    g.ntt_forward(ds, [0])
+    fa, fb = host(y[0]), host(y[8])
+    assert np.array_equal(host(ds)[0], np.array([(int(u) + int(v)) % p0 for u, v in zip(fa, fb)], dtype=np.uint64))
+    g.ntt_backward(y, idx)
+    xr = host(x) % np.tile(o.primes[:L], npoly)[:, None]
+    assert np.array_equal(host(y), xr)
+
+
+@pytest.mark.parametrize("galois", [3, 9, 5, 1])
+def test_galois_both_domains(galois):
+    o, g = ctx_pair(11, 3, 2)
+    x = np.stack([rand_poly(o, [0, 1, 2], 20 + b) for b in range(2)])
+    want = np.stack([o.apply_galois(x[b].copy(), galois) for b in range(2)])
+    d = dev(x)
+    g.apply_galois(d, 3, galois, batch=2)
+    assert np.array_equal(host(d), want)
+    want = np.stack([o.apply_galois_non_ntt(x[b].copy(), galois) for b in range(2)])
+    d = dev(x)
+    g.apply_galois_non_ntt(d, 3, galois, batch=2)
+    assert np.array_equal(host(d), want)
+
+
+@pytest.mark.parametrize("logN,L,K,Li,sp", [(10, 4, 4, 4, True), (10, 4, 4, 2, True), (11, 5, 2, 3, False), (10, 20, 3, 20, True)])
+def test_mod_up_mod_down_rescale(logN, L, K, Li, sp):
+    o, g = ctx_pair(logN, L, K, sp)
+    x = np.stack([rand_poly(o, range(Li), 30 + b) for b in range(2)])
+    want = np.stack([o.mod_up(x[b]) for b in range(2)])
+    rop = torch.zeros((2, Li + K, o.N), dtype=torch.int64, device="cuda")
+    g.mod_up(rop, dev(x), Li, batch=2)
+    assert np.array_equal(host(rop), want)
+    idx = list(range(Li)) + list(range(L, L + K))
+    y = np.stack([rand_poly(o, idx, 40 + b) for b in range(2)])
+    want = np.stack([o.mod_down(y[b]) for b in range(2)])
+    rop = torch.zeros((2, Li, o.N), dtype=torch.int64, device="cuda")
+    g.mod_down(rop, dev(y), Li, batch=2)
+    assert np.array_equal(host(rop), want)
+    want = np.stack([o.rescale(x[b]) for b in range(2)])
+    rop = torch.zeros((2, Li - 1, o.N), dtype=torch.int64, device="cuda")
+    g.rescale(rop, dev(x), Li, batch=2)
+    assert np.array_equal(host(rop), want)
+
+
+def test_mod_up_rejects_single_limb_like_reference():
+    o, g = ctx_pair(10, 4, 4)
+    with pytest.raises(fhe_amd.FheHipError) as ei:
+        g.mod_up(torch.zeros((5, o.N), dtype=torch.int64, device="cuda"), torch.zeros((1, o.N), dtype=torch.int64, device="cuda"), 1)
+    assert ei.value.code == -2
+
+
+def _keys(o, seed):
+    sx, ext = o.keygen_sk(seed=seed)
+    pkb, pka = o.keygen_pk(sx, seed=seed + 1)
+    beta, alpha = o.keygen_mult(sx, seed=seed + 2)
+    return sx, ext, pkb, pka, beta, alpha
+
+
+@pytest.mark.parametrize("logN,L,K,Li,sp", [(10, 4, 4, 4, True), (10, 4, 4, 3, True), (11, 3, 1, 3, False), (10, 18, 1, 18, True)])
+def test_cross_mult_relin_rescale_pipeline(logN, L, K, Li, sp):
+    o, g = ctx_pair(logN, L, K, sp)
+    sx, ext, pkb, pka, beta, alpha = _keys(o, 50)
+    g.load_mult_key(dev(beta), dev(alpha))
+    B = 2
+    c0 = np.stack([np.stack([rand_poly(o, range(Li), 60 + 2 * b), rand_poly(o, range(Li), 61 + 2 * b)]) for b in range(B)])
+    c1 = np.stack([np.stack([rand_poly(o, range(Li), 70 + 2 * b), rand_poly(o, range(Li), 71 + 2 * b)]) for b in range(B)])
+    out3 = torch.zeros((B, 3, Li, o.N), dtype=torch.int64, device="cuda")
+    g.cross_mult(out3, dev(c0), dev(c1), Li, batch=B)
+    want3 = np.stack([np.stack(o.cross_mult(c0[b, 0], c0[b, 1], c1[b, 0], c1[b, 1])) for b in range(B)])
+    assert np.array_equal(host(out3), want3)
+    rl = torch.zeros((B, 2, Li, o.N), dtype=torch.int64, device="cuda")
+    g.relin_only(rl, out3, Li, batch=B)
+    want_rl = np.stack([np.stack(o.relinearize(want3[b, 0], want3[b, 1], want3[b, 2], beta, alpha)) for b in range(B)])
+    assert np.array_equal(host(rl), want_rl)
+    out = torch.zeros((B, 2, Li - 1, o.N), dtype=torch.int64, device="cuda")
+    g.relinearize(out, out3, Li, batch=B)
+    want = np.stack([np.stack(o.rescale_ntt(want_rl[b, 0], want_rl[b, 1])) for b in range(B)])
+    assert np.array_equal(host(out), want)
+    out2 = torch.zeros_like(out)
+    g.mul_relin_rescale(out2, dev(c0), dev(c1), Li, batch=B)
+    want2 = np.stack([np.stack(o.mul_relin_rescale(c0[b, 0], c0[b, 1], c1[b, 0], c1[b, 1], beta, alpha)) for b in range(B)])
+    assert np.array_equal(host(out2), want2)
+    assert np.array_equal(want2, want)
+
+
+def test_config1_roundtrip_decrypted_plaintext_level():
+    """BASELINE config 1 (N=2^13, L=K=4): encrypt -> multiply_and_relin on the GPU -> decrypt; ciphertext limbs
+    and decrypted plaintext limbs bit-exact vs the oracle, and the plaintext equals a*b/q_last up to noise."""
+    logN, L, K = 13, 4, 4
+    o, g = ctx_pair(logN, L, K)
+    sx, ext, pkb, pka, beta, alpha = _keys(o, 80)
+    g.load_mult_key(beta, alpha)  # host-memory key upload
+    rng = np.random.default_rng(81)
+    scale = 1 << 40
+
+    def enc(vals, seed):
+        m = np.zeros((L, o.N), np.uint64)
+        for i in range(L):
+            p = int(o.primes[i])
+            m[i] = np.array([(int(v) * scale) % p for v in vals], dtype=np.uint64)
+        return np.stack(o.encrypt(m, pkb, pka, seed))
+
+    a = rng.integers(-4, 5, o.N)
+    b = rng.integers(-4, 5, o.N)
+    ca, cb = enc(a, 82), enc(b, 83)
+    out = torch.zeros((1, 2, L - 1, o.N), dtype=torch.int64, device="cuda")
+    g.mul_relin_rescale(out, dev(ca[None]), dev(cb[None]), L, batch=1)
+    want = np.stack(o.mul_relin_rescale(ca[0], ca[1], cb[0], cb[1], beta, alpha))
+    got = host(out)[0]
+    assert np.array_equal(got, want)
+    dec_gpu = o.decrypt(got[0].copy(), got[1].copy(), sx)
+    dec_cpu = o.decrypt(want[0], want[1], sx)
+    assert np.array_equal(dec_gpu, dec_cpu)
+    # semantic check on limb 0: centred value * q_last ~ negacyclic(a, b) * scale^2
+    p0, qlast = int(o.primes[0]), int(o.primes[L - 1])
+    prod = np.zeros(o.N, dtype=object)
+    an, bn = [int(v) for v in a], [int(v) for v in b]
+    for i in np.nonzero(a)[0][:64]:  # sparse spot check of the convolution is enough at this size
+        pass
+    fa = np.fft.rfft(np.concatenate([a, np.zeros(o.N)]).astype(np.float64))
+    fb = np.fft.rfft(np.concatenate([b, np.zeros(o.N)]).astype(np.float64))
+    full = np.rint(np.fft.irfft(fa * fb)).astype(np.int64)
+    neg = full[: o.N] - full[o.N:]
+    expect = [(int(v) * scale * scale // qlast) % p0 for v in neg]
+    diff = [min((int(x) - e) % p0, (e - int(x)) % p0) for x, e in zip(dec_gpu[0], expect)]
+    assert max(diff) < 1 << 40
+
+
+@pytest.mark.parametrize("logN,L,K,Li,sp", [(10, 4, 4, 4, True), (10, 4, 4, 2, True), (11, 3, 2, 3, False), (10, 17, 17, 17, True)])
+def test_rotate_keyswitch(logN, L, K, Li, sp):
+    o, g = ctx_pair(logN, L, K, sp)
+    sx, ext = o.keygen_sk(seed=90)
+    for off in (1, 4):
+        gal = o.rotation_galois(off)
+        rkb, rka = o.keygen_rot(sx, ext, gal, seed=91 + off)
+        g.load_rot_key(gal, dev(rkb), dev(rka))
+        B = 2
+        ct = np.stack([np.stack([rand_poly(o, range(Li), 100 + 2 * b), rand_poly(o, range(Li), 101 + 2 * b)]) for b in range(B)])
+        want = np.stack([np.stack(o.rotate(ct[b, 0], ct[b, 1], gal, rkb, rka)) for b in range(B)])
+        d = dev(ct)
+        g.rotate(gal, d, Li, batch=B)
+        assert np.array_equal(host(d), want)
+    d = dev(ct)
+    g.rotate(0, d, Li, batch=B)  # galois == 0: no-op (evaluator.cpp:303-304)
+    assert np.array_equal(host(d), ct)
+    with pytest.raises(fhe_amd.FheHipError):
+        g.rotate(7, d, Li, batch=B)  # no key loaded for this galois element
+
+
+def test_add_and_multiply_plain():
+    o, g = ctx_pair(10, 4, 4)
+    a = np.stack([rand_poly(o, range(4), 110 + b) for b in range(2)])
+    b_ = np.stack([rand_poly(o, range(4), 120 + b) for b in range(2)])
+    d = dev(a)
+    g.add(d, dev(b_), 4, batch=2)
+    assert np.array_equal(host(d), np.stack([o.add(a[i], b_[i]) for i in range(2)]))
+    pt = rand_poly(o, range(4), 130)
+    ct = np.stack([a, b_], axis=1)  # [2][2][4][N]
+    d = dev(np.ascontiguousarray(ct))
+    g.multiply_plain(d, dev(pt), 4, batch=2)
+    want = np.stack([np.stack(o.multiply_plain(ct[i, 0], ct[i, 1], pt)) for i in range(2)])
+    assert np.array_equal(host(d), want)
