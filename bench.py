@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the fHE RNS-CKKS hot path on MI355X (contract: see task brief / DESIGN.md §Measurement).
+
+A "step" is one pass of the hot path over one batch of synthetic, HBM-resident input:
+  --workload c3  (default; BASELINE.json configs[2], the config the metric is quoted on):
+                 N=2^16, Li=L=30 ciphertext multiply + relinearize + rescale, `--batch` ops per step
+  --workload ntt batched forward limb-NTT, N=2^16 (north_star headline kernel), `--batch` limbs per step
+  --workload c2  N=2^14, 8 limbs x 1024 polys forward+inverse NTT
+  --workload c4  N=2^16, Li=K=30 rotation key switch
+  --workload c5  N=2^15, Li=16 multiply+relin+rescale
+One rank per GPU (torch.distributed / RCCL is used only for the barrier and the max-over-ranks of the time:
+independent ciphertexts shard with no data-path collective -> "scaling": "weak").
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    #        logN  L   K   Li  default batch
+    "c3": (16, 30, 1, 30, 4),
+    "c5": (15, 16, 1, 16, 16),
+    "c4": (16, 30, 30, 30, 4),
+    "ntt": (16, 8, 0, 8, 512),
+    "c2": (14, 8, 0, 8, 8192),
+}
+
+
+def gen_primes_host(logN, count):
+    """The repo's prime table (same rule as oracle/fhe_oracle.c:orc_gen_primes) without touching the oracle."""
+    def is_prime(n):
+        if n < 2:
+            return False
+        small = (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37)
+        for q in small:
+            if n % q == 0:
+                return n == q
+        d, r = n - 1, 0
+        while d % 2 == 0:
+            d //= 2
+            r += 1
+        for a in small:
+            x = pow(a, d, n)
+            if x in (1, n - 1):
+                continue
+            for _ in range(r - 1):
+                x = x * x % n
+                if x == n - 1:
+                    break
+            else:
+                return False
+        return True
+
+    pr, ps = [], []
+    k = (1 << 30) - 1
+    while len(pr) < count:
+        p = (k << 32) + 1
+        k -= 1
+        if not is_prime(p):
+            continue
+        x = 2
+        while pow(x, (p - 1) // 2, p) != p - 1:
+            x += 1
+        pr.append(p)
+        ps.append(pow(x, (p - 1) >> (logN + 1), p))
+    return np.array(pr, np.uint64), np.array(ps, np.uint64)
+
+
+def algorithmic_bytes(workload, N, Li, K):
+    """SURVEY.md §8(d) per-unit algorithmic bytes (8-byte limbs)."""
+    if workload in ("c3", "c5"):
+        return 8 * N * (2 * Li * Li + 6 * Li - 2)
+    if workload == "c4":
+        return 8 * N * (6 * Li + 2 * K)
+    return 16 * N  # one limb-NTT
+
+
+def cpu_baseline(workload, logN, L, K, Li, inputs, budget_s=20.0):
+    """Times the CPU oracle (kind "port": restatement of the reference's loop structure) on rank 0's host cores,
+    single thread like the reference, on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    pr, ps = inputs["primes"], inputs["psi"]
+    o = orc.Oracle(logN, L, K, pr, ps)
+    N = 1 << logN
+    t_used, units = 0.0, 0
+    if workload in ("c3", "c5"):
+        c0, c1, beta, alpha = inputs["c0"], inputs["c1"], inputs["beta"], inputs["alpha"]
+        while t_used < budget_s and units < c0.shape[0]:
+            t0 = time.perf_counter()
+            o.mul_relin_rescale(c0[units, 0], c0[units, 1], c1[units, 0], c1[units, 1], beta, alpha)
+            t_used += time.perf_counter() - t0
+            units += 1
+        unit = "ct-mult+relin+rescale/s"
+        sample = "%d op(s) of the bench batch, N=2^%d Li=%d" % (units, logN, Li)
+    elif workload == "c4":
+        ct, rkb, rka, gal = inputs["ct"], inputs["rkb"], inputs["rka"], inputs["galois"]
+        while t_used < budget_s and units < ct.shape[0]:
+            t0 = time.perf_counter()
+            o.rotate(ct[units, 0], ct[units, 1], gal, rkb, rka)
+            t_used += time.perf_counter() - t0
+            units += 1
+        unit = "rotation-keyswitch/s"
+        sample = "%d op(s) of the bench batch, N=2^%d Li=K=%d" % (units, logN, Li)
+    else:
+        x, idx = inputs["x"], inputs["idx"]
+        n = min(x.shape[0], 256)
+        t0 = time.perf_counter()
+        o.ntt_forward(x[:n].copy(), idx[:n])
+        t_used = time.perf_counter() - t0
+        units = n
+        unit = "limb-NTT/s"
+        sample = "%d forward limb-NTTs of the bench batch, N=2^%d" % (n, logN)
+    return {"value": units / t_used, "unit": unit, "cores": 1, "kind": "port", "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="units per step per GPU (0 = workload default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import fhe_amd
+    logN, L, K, Li, dflt_batch = WORKLOADS[args.workload]
+    B = args.batch or dflt_batch
+    N = 1 << logN
+    primes, psi = gen_primes_host(logN, L + K)
+    ctx = fhe_amd.HipContext(logN, L, K, primes, psi, device=local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # synthetic inputs, resident in HBM: uniform residues below 2^61 (< every prime of the table)
+    gen = torch.Generator(device="cuda").manual_seed(0x5EED0000 + rank)
+
+    def rnd(*shape):
+        return torch.randint(0, 1 << 61, shape, dtype=torch.int64, device="cuda", generator=gen)
+
+    inputs = {"primes": primes, "psi": psi}
+    dominant = None
+    if args.workload in ("c3", "c5"):
+        c0, c1 = rnd(B, 2, Li, N), rnd(B, 2, Li, N)
+        beta, alpha = rnd(L, L, N), rnd(L, L, N)
+        out = torch.empty((B, 2, Li - 1, N), dtype=torch.int64, device="cuda")
+        ctx.load_mult_key(beta, alpha)
+        step = lambda: ctx.mul_relin_rescale(out, c0, c1, Li, batch=B)  # noqa: E731
+        metric, unit = "ct-mult+relin+rescale/sec at N=2^%d, Li=%d" % (logN, Li), "ops/s"
+        dominant = ("ntt_fwd_cols", "ntt_fwd_rows")
+    elif args.workload == "c4":
+        ct = rnd(B, 2, Li, N)
+        rkb, rka = rnd(L + K, N), rnd(L + K, N)
+        galois = 3
+        ctx.load_rot_key(galois, rkb, rka)
+        work = ct.clone()
+        step = lambda: ctx.rotate(galois, work, Li, batch=B)  # noqa: E731
+        metric, unit = "rotation-keyswitch/sec at N=2^%d, Li=K=%d" % (logN, Li), "ops/s"
+        dominant = ("bconv_modup", "bconv_moddown")
+    else:
+        x = rnd(B, N)
+        idx = np.tile(np.arange(L, dtype=np.uint32), (B + L - 1) // L)[:B]
+        if args.workload == "c2":
+            def step():
+                ctx.ntt_forward(x, idx)
+                ctx.ntt_backward(x, idx)
+            per_step_units = 2 * B
+        else:
+            step = lambda: ctx.ntt_forward(x, idx)  # noqa: E731
+            per_step_units = B
+        metric, unit = "limb-NTTs/sec at N=2^%d" % logN, "limb-NTT/s"
+        dominant = ("ntt_fwd_cols", "ntt_fwd_rows")
+    units_per_step = B if args.workload in ("c3", "c4", "c5") else per_step_units
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    value = units_per_step * args.steps * world / elapsed
+    alg = algorithmic_bytes(args.workload, N, Li, K)
+
+    # roofline of the dominant kernel (pair): algorithmic bytes per launch / average launch duration,
+    # durations from HIP events recorded on the launch stream inside the timed region.
+    roofline = None
+    if dominant:
+        ms = sum(prof.get(k, (0, 0.0))[1] for k in dominant)
+        launches = max(prof.get(k, (0, 0.0))[0] for k in dominant) if any(k in prof for k in dominant) else 0
+        if launches and ms > 0:
+            if dominant[0].startswith("ntt"):
+                # every limb-NTT is one cols + one rows pass; count limb-NTTs done by these launches in the region
+                if args.workload in ("c3", "c5"):
+                    limb_ntts = (Li * Li + 2 * (Li - 1) + 0) * units_per_step * args.steps  # forward NTTs only
+                else:
+                    limb_ntts = B * args.steps
+                alg_total = limb_ntts * 16 * N
+                kname = "ntt_fwd (cols+rows pair)"
+            else:
+                alg_total = units_per_step * args.steps * 8 * N * (Li + K) * 2  # conversion in/out limbs, informational
+                kname = "+".join(dominant)
+            achieved = alg_total / (ms * 1e-3) / 1e9
+            pair_launches = launches
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                        "alg_bytes_per_launch": alg_total / pair_launches, "avg_launch_ms": ms / pair_launches,
+                        "launches": pair_launches}
+
+    result = {
+        "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "%s: N=2^%d Li=%d K=%d, %d units/step/GPU" % (args.workload, logN, Li, K, units_per_step),
+                   "parallelism": "independent ciphertexts sharded over %d GPU(s), no data-path collective" % world},
+        "roofline_whole_op": {"alg_bytes_per_unit": alg, "achieved_GBs": value / world * alg / 1e9,
+                              "frac_of_hbm_peak": value / world * alg / 1e9 / HBM_PEAK_GBS},
+        "kernel_ms": {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in sorted(prof.items())},
+    }
+    if roofline:
+        result["roofline"] = roofline
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if args.workload in ("c3", "c5"):
+            nb = min(B, 2)
+            inputs.update(c0=c0[:nb].cpu().numpy().view(np.uint64), c1=c1[:nb].cpu().numpy().view(np.uint64),
+                          beta=beta.cpu().numpy().view(np.uint64), alpha=alpha.cpu().numpy().view(np.uint64))
+        elif args.workload == "c4":
+            nb = min(B, 2)
+            inputs.update(ct=ct[:nb].cpu().numpy().view(np.uint64), rkb=rkb.cpu().numpy().view(np.uint64),
+                          rka=rka.cpu().numpy().view(np.uint64), galois=galois)
+        else:
+            inputs.update(x=rnd(min(B, 256), N).cpu().numpy().view(np.uint64), idx=idx)
+        result["cpu_baseline"] = cpu_baseline(args.workload, logN, L, K, Li, inputs, args.cpu_budget)
+
+    if rank == 0:
+        print(json.dumps(result))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -22,6 +22,27 @@ class FheHipError(RuntimeError):
         self.code = code
 
 
+def _load_hip_runtime():
+    """libfhe_hip.so carries no NEEDED entry for the HIP runtime (built with -no-hip-rt): make the process's
+    runtime visible first.  Inside a PyTorch process that is the libamdhip64 PyTorch ships, so tensors, streams
+    and events are shared with torch; otherwise the system ROCm runtime."""
+    candidates = []
+    try:
+        import torch
+        candidates.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    candidates += ["/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
+    for path in candidates:
+        if os.path.isabs(path) and not os.path.exists(path):
+            continue
+        try:
+            return C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            continue
+    raise OSError("no HIP runtime (libamdhip64) found")
+
+
 def load_library():
     """Load libfhe_hip.so; raises if it has not been built (no fallback of any kind)."""
     global _lib
@@ -30,6 +51,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(
             "%s not found: build it with `make -C fhe_amd/csrc` (or python -c 'import __graft_entry__ as g; g.build()')" % LIB_PATH)
+    _load_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp, u32, u64, i, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_size_t
     sig = {
