@@ -166,6 +166,8 @@ struct NttPlan {
   u32 nl;        // limbs per batch entry
   u32 batch;
   u64 src_bstride, dst_bstride;
+  u32 skip_diag = 0;
+  bool cols_only = false;  // forward only: stop after the column pass (the row pass is fused elsewhere)
 };
 
 template <bool SP, bool INV>
@@ -199,7 +201,7 @@ int ntt_run_sp(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
   NttArgs a;
   a.tw = inverse ? c->d_tw_inv : c->d_tw_fwd;
   a.primes = c->d_primes; a.midx = p.midx; a.mdiv = p.mdiv; a.mper = p.mper;
-  a.logN = c->logN; a.logR = c->logR;
+  a.logN = c->logN; a.logR = c->logR; a.l0 = 0; a.skip_diag = p.skip_diag;
   a.dst = p.dst; a.dst_bstride = p.dst_bstride;
   // first pass reads the (possibly broadcast) source, second pass runs in place on dst
   NttArgs first = a, second = a;
@@ -207,7 +209,7 @@ int ntt_run_sp(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
   second.src = p.dst; second.src_bstride = p.dst_bstride; second.smod = p.nl;
   if (!inverse) {
     TRY((launch_cols<SP, false>(c, first, p.nl, p.batch)));
-    TRY((launch_rows<SP, false>(c, second, p.nl, p.batch)));
+    if (!p.cols_only) TRY((launch_rows<SP, false>(c, second, p.nl, p.batch)));
   } else {
     TRY((launch_rows<SP, true>(c, first, p.nl, p.batch)));
     TRY((launch_cols<SP, true>(c, second, p.nl, p.batch)));
@@ -341,11 +343,17 @@ int dev_relin(fhe_hip_ctx *c, u64 *out, const u64 *ct3, u32 Li, u32 batch) {
     // ct2_power = INTT(ct[2])   (evaluator.cpp:659-660)
     NttPlan pi{in + (size_t)2 * Li * N, pw, c->d_iota, 1, Li, Li, Li, nb, (u64)3 * Li * N, (u64)Li * N};
     TRY(ntt_run(c, pi, true));
-    // t[i][j] = NTT_i(ct2_power[j])   (evaluator.cpp:666-668), limb id = i*Li + j
+    // column pass of t[i][j] = NTT_i(ct2_power[j]) (evaluator.cpp:666-668), limb id = i*Li + j, j == i skipped;
+    // the row pass, the key MAC (:672-679) and the final "+ ct[l]" (:682-691) are fused in relin_rows_mac_kernel
     NttPlan pf{pw, t, c->d_iota, Li, Li, Li, Li * Li, nb, (u64)Li * N, (u64)Li * Li * N};
+    pf.skip_diag = Li; pf.cols_only = true;
     TRY(ntt_run(c, pf, false));
-    LAUNCH_SP(c, "relin_mac", relin_mac_kernel, pw_grid(c, Li, nb), dim3(PW_THREADS), out + (size_t)b0 * 2 * Li * N, (const u64 *)t, in,
-              (const u64 *)c->d_mk_beta, (const u64 *)c->d_mk_alpha, (const PrimeC *)c->d_primes, Li, c->L, N);
+    RelinArgs ra;
+    ra.t1 = t; ra.ct3 = in; ra.out = out + (size_t)b0 * 2 * Li * N;
+    ra.beta_m = c->d_mk_beta; ra.alpha_m = c->d_mk_alpha; ra.tw = c->d_tw_fwd; ra.primes = c->d_primes;
+    ra.Li = Li; ra.L = c->L; ra.logN = c->logN; ra.logR = c->logR; ra.i0 = 0;
+    const u32 R = 1u << c->logR, rows = R < 16 ? R : 16;
+    LAUNCH_SP(c, "relin_rows_mac", relin_rows_mac_kernel, dim3(R / rows, Li, nb), dim3(16 * rows), ra);
   }
   return FHE_HIP_OK;
 }

@@ -23,8 +23,17 @@ struct NttArgs {
   u32 mdiv, mper;
   u32 smod;             // source limb = l % smod (broadcast of a source limb over several outputs)
   u32 logN, logR;
+  u32 l0;               // limb offset: limb id = blockIdx.y + l0
+  u32 skip_diag;        // if nonzero (= Li): skip limbs with (l / Li) == (l % Li)  (relinearisation, j == i)
   u64 src_bstride, dst_bstride;  // elements between batch entries
 };
+
+// LDS hand-off inside one wave (a 256-element row is owned by 16 consecutive lanes of one wave)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __device__ __forceinline__ u64 canon4(u64 v, const PrimeC &P) { return csub(csub(v, P.twop), P.p); }
 
@@ -74,7 +83,7 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
   const u32 tid = threadIdx.x, rloc = tid >> 4, t = tid & 15;
   const u32 rows_per_wg = blockDim.x >> 4;
   const u32 row = blockIdx.x * rows_per_wg + rloc;
-  const u32 l = blockIdx.y, b = blockIdx.z;
+  const u32 l = blockIdx.y + a.l0, b = blockIdx.z;
   const u32 m = a.midx[(l / a.mdiv) % a.mper];
   const PrimeC P = a.primes[m];
   const u64 N = 1ull << a.logN;
@@ -158,7 +167,8 @@ __global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs
   constexpr int R = Cfg::R, LA = Cfg::LA, LB = Cfg::LB, CT = Cfg::CT, CS = Cfg::CS, T = Cfg::THREADS;
   __shared__ u64 lds[R * CS];
   const u32 tid = threadIdx.x;
-  const u32 l = blockIdx.y, b = blockIdx.z;
+  const u32 l = blockIdx.y + a.l0, b = blockIdx.z;
+  if (a.skip_diag && (l / a.skip_diag) == (l % a.skip_diag)) return;
   const u32 m = a.midx[(l / a.mdiv) % a.mper];
   const PrimeC P = a.primes[m];
   const u64 N = 1ull << a.logN;
@@ -224,5 +234,96 @@ __global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs
         for (int k = 0; k < (1 << LA); ++k) d[(u64)(g + G * k) * 256 + c] = csub(mont_mul<SP>(P.ninv_m, e[k], P), P.p);
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused relinearisation row pass (reference src/evaluator.cpp:663-691): for output limb i and a block of
+// rows, loop over the digits j: finish NTT_i(ct2_power[j]) (stages logR..logN-1 of the column-pass output
+// t1[i][j]), multiply by evk.beta_j[i] / evk.alpha_j[i] and accumulate; then add ct[0]/ct[1] and store.
+// The Li^2 NTT outputs never reach HBM and the twiddles of (i, row) are reused for all j.  For j == i the
+// NTT is the identity on ct[2] limb i (NTT_i(INTT_i(x)) = x), so it is read directly.
+// t1 = [b][Li(i)][Li(j)][N]; ct3 = [b][3][Li][N]; out = [b][2][Li][N]; keys [L][L][N] Montgomery form.
+// ---------------------------------------------------------------------------------------------
+struct RelinArgs {
+  const u64 *t1; const u64 *ct3; u64 *out;
+  const u64 *beta_m, *alpha_m;
+  const u64 *tw; const PrimeC *primes;
+  u32 Li, L, logN, logR, i0;
+};
+
+template <bool SP>
+__global__ __launch_bounds__(256) void relin_rows_mac_kernel(RelinArgs a) {
+  __shared__ __attribute__((aligned(16))) u64 lds[16 * ROW_LDS];
+  const u32 tid = threadIdx.x, rloc = tid >> 4, t = tid & 15;
+  const u32 rows_per_wg = blockDim.x >> 4;
+  const u32 row = blockIdx.x * rows_per_wg + rloc;
+  const u32 i = blockIdx.y + a.i0, b = blockIdx.z;
+  const u32 Li = a.Li;
+  const PrimeC P = a.primes[i];
+  const u64 N = 1ull << a.logN;
+  const u64 *__restrict__ tw = a.tw + (u64)i * N;
+  u64 *L = lds + rloc * ROW_LDS;
+  const u32 baseA = (1u << a.logR) + row;
+  const u64 row_off = (u64)row * 256;
+  u64 acc0[16], acc1[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { acc0[k] = 0; acc1[k] = 0; }
+  for (u32 j = 0; j < Li; ++j) {
+    u64 x[16];
+    if (j == i) {
+      const u64 *s = a.ct3 + (((u64)b * 3 + 2) * Li + i) * N + row_off;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&s[32 * q + 2 * t]);
+        x[2 * q] = v.x; x[2 * q + 1] = v.y;
+      }
+    } else {
+      const u64 *s = a.t1 + (((u64)b * Li + i) * Li + j) * N + row_off;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = s[t + 16 * k];
+      fwd_phase<SP, 4>(x, tw, baseA, P);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) L[k * 18 + t] = x[k];
+      wave_lds_sync();
+#pragma unroll
+      for (int k = 0; k < 16; k += 2) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[t * 18 + k]);
+        x[k] = v.x; x[k + 1] = v.y;
+      }
+      fwd_phase<SP, 4>(x, tw, (baseA << 4) + t, P);
+      wave_lds_sync();
+#pragma unroll
+      for (int k = 0; k < 16; k += 2) *reinterpret_cast<ulonglong2 *>(&L[t * 18 + k]) = make_ulonglong2(x[k], x[k + 1]);
+      wave_lds_sync();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[(2 * q + (t >> 3)) * 18 + ((2 * t) & 15)]);
+        x[2 * q] = v.x; x[2 * q + 1] = v.y;
+      }
+      wave_lds_sync();
+    }
+    // key MAC in the coalesced layout: lane t owns elements {32q + 2t, 32q + 2t + 1}; x may be lazy (< 4p)
+    const u64 koff = ((u64)j * a.L + i) * N + row_off;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(&a.beta_m[koff + 32 * q + 2 * t]);
+      const ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(&a.alpha_m[koff + 32 * q + 2 * t]);
+      acc0[2 * q] = csub(acc0[2 * q] + mont_mul<SP>(kb.x, x[2 * q], P), P.twop);
+      acc0[2 * q + 1] = csub(acc0[2 * q + 1] + mont_mul<SP>(kb.y, x[2 * q + 1], P), P.twop);
+      acc1[2 * q] = csub(acc1[2 * q] + mont_mul<SP>(ka.x, x[2 * q], P), P.twop);
+      acc1[2 * q + 1] = csub(acc1[2 * q + 1] + mont_mul<SP>(ka.y, x[2 * q + 1], P), P.twop);
+    }
+  }
+  const u64 half = (u64)Li * N;
+  const u64 *c = a.ct3 + ((u64)b * 3 * Li + i) * N + row_off;
+  u64 *o = a.out + ((u64)b * 2 * Li + i) * N + row_off;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const u32 e = 32 * q + 2 * t;
+    const ulonglong2 d0 = *reinterpret_cast<const ulonglong2 *>(&c[e]);
+    const ulonglong2 d1 = *reinterpret_cast<const ulonglong2 *>(&c[half + e]);
+    *reinterpret_cast<ulonglong2 *>(&o[e]) = make_ulonglong2(csub(csub(acc0[2 * q], P.p) + d0.x, P.p), csub(csub(acc0[2 * q + 1], P.p) + d0.y, P.p));
+    *reinterpret_cast<ulonglong2 *>(&o[half + e]) = make_ulonglong2(csub(csub(acc1[2 * q], P.p) + d1.x, P.p), csub(csub(acc1[2 * q + 1], P.p) + d1.y, P.p));
   }
 }
