@@ -78,13 +78,36 @@ __device__ __forceinline__ void mac128(u64 &hi, u64 &lo, u64 a, u64 b) {
   hi += h + (lo < l ? 1 : 0);
 }
 
-// Harvey lazy Cooley-Tukey butterfly: X, Y in [0,4p) -> [0,4p);  W in Montgomery form
+// thi - w of the Montgomery product a*b (a < p Montgomery-form constant, b any 64-bit value): a signed value in
+// (-p, p), returned mod 2^64.  mont_mul(a, b) == mont_diff(a, b) + p.
+template <bool SP>
+__device__ __forceinline__ u64 mont_diff(u64 a, u64 b, const PrimeC &P) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  const u64 t0 = mad_wide(a0, b0, 0);
+  const u64 t1 = mad_wide(a0, b1, t0 >> 32);
+  const u64 t2 = mad_wide(a1, b0, (u64)(u32)t1);
+  const u64 thi = mad_wide(a1, b1, (t1 >> 32) + (t2 >> 32));
+  if constexpr (SP) {
+    const u32 T0 = (u32)t0, T1 = (u32)t2;
+    const u64 v = mad_wide(T0, P.p1, 0);
+    const u32 vlo = (u32)v;
+    const u32 m1 = T1 - vlo;
+    const u32 u = (u32)(v >> 32) + (T1 < vlo ? 1u : 0u);  // carry of vlo + m1 == borrow of T1 - vlo
+    return thi - mad_wide(m1, P.p1, (u64)u);
+  } else {
+    const u64 tlo = (t2 << 32) | (u64)(u32)t0;
+    return thi - __umul64hi(tlo * P.pinv, P.p);
+  }
+}
+
+// Harvey lazy Cooley-Tukey butterfly: X, Y in [0,4p) -> (0,4p);  W in Montgomery form.
+// With D = mont_diff(W, Y) in (-p, p) and xp = (X mod 2p) + p in [p, 3p):  X' = xp + D, Y' = xp - D.
 template <bool SP>
 __device__ __forceinline__ void ct_bfly(u64 &X, u64 &Y, u64 W, const PrimeC &P) {
-  const u64 x = csub(X, P.twop);
-  const u64 t = mont_mul<SP>(W, Y, P);  // (0, 2p)
-  X = x + t;
-  Y = x - t + P.twop;
+  const u64 D = mont_diff<SP>(W, Y, P);
+  const u64 xp = (X >= P.twop) ? X - P.p : X + P.p;
+  X = xp + D;
+  Y = xp - D;
 }
 
 // lazy Gentleman-Sande butterfly: X, Y in [0,2p) -> [0,2p)
@@ -93,5 +116,5 @@ __device__ __forceinline__ void gs_bfly(u64 &X, u64 &Y, u64 W, const PrimeC &P) 
   const u64 s = X + Y;
   const u64 d = X - Y + P.twop;
   X = csub(s, P.twop);
-  Y = mont_mul<SP>(W, d, P);
+  Y = mont_diff<SP>(W, d, P) + P.p;
 }

@@ -44,11 +44,19 @@ __device__ __forceinline__ void fwd_phase(u64 (&e)[1 << LK], const u64 *__restri
     const int half = 1 << (LK - 1 - q);
 #pragma unroll
     for (int kk = 0; kk < (1 << q); ++kk) {
+#if defined(NTT_ABL) && NTT_ABL == 3
+      const u64 W = P.r2 + base + kk;
+#else
       const u64 W = tw[(base << q) + kk];
+#endif
 #pragma unroll
       for (int j = 0; j < half; ++j) {
         const int a = kk * 2 * half + j;
+#if defined(NTT_ABL) && NTT_ABL == 1
+        e[a] += W; e[a + half] ^= W;
+#else
         ct_bfly<SP>(e[a], e[a + half], W, P);
+#endif
       }
     }
   }
@@ -96,11 +104,15 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
   if constexpr (!INVERSE) {
     // phase A: spans 128..16, thread holds {t + 16k}
 #pragma unroll
+#if defined(NTT_ABL) && NTT_ABL == 2
+    for (int k = 0; k < 16; ++k) e[k] = (u64)tid * 0x9E3779B97F4A7C15ull + k + P.r2;
+#else
     for (int k = 0; k < 16; ++k) e[k] = s[t + 16 * k];
+#endif
     fwd_phase<SP, 4>(e, tw, baseA, P);
 #pragma unroll
     for (int k = 0; k < 16; ++k) L[k * 18 + t] = e[k];
-    __syncthreads();
+    wave_lds_sync();
     // phase B: spans 8..1, thread holds {16t + k}
 #pragma unroll
     for (int k = 0; k < 16; k += 2) {
@@ -110,15 +122,19 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
     fwd_phase<SP, 4>(e, tw, (baseA << 4) + t, P);
 #pragma unroll
     for (int k = 0; k < 16; ++k) e[k] = canon4(e[k], P);
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int k = 0; k < 16; k += 2) *reinterpret_cast<ulonglong2 *>(&L[t * 18 + k]) = make_ulonglong2(e[k], e[k + 1]);
-    __syncthreads();
+    wave_lds_sync();
     // coalesced 16-byte stores: instruction i covers elements [32i, 32i+32) of the row
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[(2 * i + (t >> 3)) * 18 + ((2 * t) & 15)]);
+#if defined(NTT_ABL) && NTT_ABL == 2
+      if (v.x == 0x123456789ull) d[32 * i + 2 * t] = v.y;
+#else
       *reinterpret_cast<ulonglong2 *>(&d[32 * i + 2 * t]) = v;
+#endif
     }
   } else {
     // inverse: spans 1..8 first (thread holds {16t + k}), then spans 16..128 ({t + 16k}); output lazy [0,2p)
@@ -127,17 +143,17 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
       const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&s[32 * i + 2 * t]);
       *reinterpret_cast<ulonglong2 *>(&L[(2 * i + (t >> 3)) * 18 + ((2 * t) & 15)]) = v;
     }
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int k = 0; k < 16; k += 2) {
       const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[t * 18 + k]);
       e[k] = v.x; e[k + 1] = v.y;
     }
     inv_phase<SP, 4>(e, tw, (baseA << 4) + t, P);
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int k = 0; k < 16; k += 2) *reinterpret_cast<ulonglong2 *>(&L[t * 18 + k]) = make_ulonglong2(e[k], e[k + 1]);
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int k = 0; k < 16; ++k) e[k] = L[k * 18 + t];
     inv_phase<SP, 4>(e, tw, baseA, P);

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libfhe_hip.so")
+LIB_PATH = os.environ.get("FHE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libfhe_hip.so")
 
 MEM_DEVICE, MEM_HOST = 0, 1
 

@@ -1,0 +1,155 @@
+// fHE/evaluator.hpp — public interface of reference include/fHE/evaluator.hpp:12-40.  The reference's pimpl
+// (src/evaluator.cpp:12-68) is replaced by calls into the gfx950 C-ABI; error conventions are kept: in place on
+// rop, false + one std::cerr line on misuse (evaluator.cpp:130-134, 275-283, 581-584).
+#pragma once
+#include "fHE/base_converter.hpp"
+#include "fHE/cipher.hpp"
+#include "fHE/mult_key.hpp"
+#include "fHE/rot_key.hpp"
+namespace fHE {
+struct Encoder;
+struct Evaluator {
+ private:
+  std::shared_ptr<Encoder> encoder;
+  mutable const MultKey *loaded_mkey_ = nullptr;
+  mutable std::unordered_map<size_t, const RotKey *> loaded_rkeys_;
+  using T = yell::params::value_type;
+
+  static fhe_hip_ctx *ctx() { return yell::runtime::get().ctx; }
+  static void pack(std::vector<T> &buf, size_t off, context::poly_t const &p, size_t n) { std::memcpy(buf.data() + off, p.cptr_at(0), n * context::degree * sizeof(T)); }
+  bool ensure_mult_key(MultKey const &mkey) const {
+    if (loaded_mkey_ == &mkey) return true;
+    const size_t L = context::nr_ctxt_moduli, N = context::degree;
+    std::vector<T> beta(L * L * N), alpha(L * L * N);
+    for (size_t j = 0; j < L; ++j) { pack(beta, j * L * N, *mkey.get_beta_at(j), L); pack(alpha, j * L * N, *mkey.get_alpha_at(j), L); }
+    if (fhe_hip_load_mult_key(ctx(), beta.data(), alpha.data(), FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
+    loaded_mkey_ = &mkey;
+    return true;
+  }
+  bool ensure_rot_key(RotKey const &rkey) const {
+    auto it = loaded_rkeys_.find(rkey.galois);
+    if (it != loaded_rkeys_.end() && it->second == &rkey) return true;
+    if (fhe_hip_load_rot_key(ctx(), rkey.galois, rkey.beta.cptr_at(0), rkey.alpha.cptr_at(0), FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
+    loaded_rkeys_[rkey.galois] = &rkey;
+    return true;
+  }
+
+ public:
+  explicit Evaluator(std::shared_ptr<Encoder> encoder = nullptr) : encoder(encoder) {}
+  ~Evaluator() {}
+
+  bool add(Cipher *rop, Cipher const &c1) const {  // Impl::add_inplace, evaluator.cpp:270-297
+    if (!rop) return false;
+    if (rop->moduli_count() != c1.moduli_count()) { std::cerr << "Can not add_inplace." << std::endl; return false; }
+    if (!rop->canonical() && c1.canonical()) { std::cerr << "Can not add_inplace" << std::endl; return false; }
+    const uint32_t n = (uint32_t)rop->moduli_count();
+    bool ok = fhe_hip_add(ctx(), rop->bx.ptr_at(0), c1.bx.cptr_at(0), n, 1, FHE_HIP_MEM_HOST) == FHE_HIP_OK &&
+              fhe_hip_add(ctx(), rop->ax.ptr_at(0), c1.ax.cptr_at(0), n, 1, FHE_HIP_MEM_HOST) == FHE_HIP_OK;
+    if (!c1.canonical()) {
+      if (rop->canonical()) rop->mul_aux = std::make_shared<context::poly_t>(*c1.mul_aux);
+      else ok = ok && fhe_hip_add(ctx(), rop->mul_aux->ptr_at(0), c1.mul_aux->cptr_at(0), n, 1, FHE_HIP_MEM_HOST) == FHE_HIP_OK;
+    }
+    if (rop->scale() == 1.) rop->scale(c1.scale());
+    return ok;
+  }
+
+  bool multiply(Cipher *rop, Cipher const &c1) const {  // Impl::multiply_inplace, evaluator.cpp:576-597
+    if (!rop) return false;
+    if (rop->moduli_count() != c1.moduli_count() || !(rop->canonical() && c1.canonical())) { std::cerr << "Can not multiply_inplace" << std::endl; return false; }
+    const size_t Li = rop->moduli_count(), N = context::degree, limbs = Li * N;
+    const double new_scale = rop->scale() / yell::params::P[Li - 1] * c1.scale();
+    std::vector<T> in0(2 * limbs), in1(2 * limbs), out(3 * limbs);
+    pack(in0, 0, rop->bx, Li); pack(in0, limbs, rop->ax, Li); pack(in1, 0, c1.bx, Li); pack(in1, limbs, c1.ax, Li);
+    if (fhe_hip_cross_mult(ctx(), out.data(), in0.data(), in1.data(), (uint32_t)Li, 1, FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
+    std::memcpy(rop->bx.ptr_at(0), out.data(), limbs * sizeof(T));
+    std::memcpy(rop->ax.ptr_at(0), out.data() + limbs, limbs * sizeof(T));
+    rop->mul_aux = std::make_shared<context::poly_t>(Li);
+    std::memcpy(rop->mul_aux->ptr_at(0), out.data() + 2 * limbs, limbs * sizeof(T));
+    rop->scale(new_scale);
+    return true;
+  }
+
+  bool multiply_plain(Cipher *rop, context::poly_t const &p, const double plain_scale = -1) const {  // evaluator.cpp:88-111
+    if (!rop) return false;
+    const size_t nm = p.moduli_count(), N = context::degree;
+    if (rop->moduli_count() != nm) return false;
+    std::vector<T> ct(2 * nm * N);
+    pack(ct, 0, rop->bx, nm); pack(ct, nm * N, rop->ax, nm);
+    if (fhe_hip_multiply_plain(ctx(), ct.data(), p.cptr_at(0), (uint32_t)nm, 1, FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
+    std::memcpy(rop->bx.ptr_at(0), ct.data(), nm * N * sizeof(T));
+    std::memcpy(rop->ax.ptr_at(0), ct.data() + nm * N, nm * N * sizeof(T));
+    if (plain_scale > 0.) rop->scale(rop->scale() * plain_scale);
+    return true;
+  }
+
+  bool relinearize(Cipher *rop, MultKey const &mkey) const {  // Impl::relinerize_inplace (relin + rescale), evaluator.cpp:599-619
+    if (!rop) return false;
+    if (rop->canonical()) return false;
+    const size_t Li = rop->moduli_count(), N = context::degree, limbs = Li * N;
+    if (Li < 2 || !ensure_mult_key(mkey)) return false;
+    std::vector<T> in(3 * limbs), out(2 * (Li - 1) * N);
+    pack(in, 0, rop->bx, Li); pack(in, limbs, rop->ax, Li); pack(in, 2 * limbs, *rop->mul_aux, Li);
+    if (fhe_hip_relinearize(ctx(), out.data(), in.data(), (uint32_t)Li, 1, FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
+    const double s = rop->scale();
+    Cipher tmp(Li - 1);
+    std::memcpy(tmp.bx.ptr_at(0), out.data(), (Li - 1) * N * sizeof(T));
+    std::memcpy(tmp.ax.ptr_at(0), out.data() + (Li - 1) * N, (Li - 1) * N * sizeof(T));
+    rop->bx = std::move(tmp.bx); rop->ax = std::move(tmp.ax); rop->mul_aux = nullptr;
+    rop->scale(s);
+    return true;
+  }
+
+  bool multiply_and_relin(Cipher *rop, Cipher const &c1, MultKey const &mkey) const {  // evaluator.cpp:119-126, one fused device call
+    if (!rop) return false;
+    if (rop->moduli_count() != c1.moduli_count() || !(rop->canonical() && c1.canonical())) { std::cerr << "Can not multiply_inplace" << std::endl; return false; }
+    const size_t Li = rop->moduli_count(), N = context::degree, limbs = Li * N;
+    if (Li < 2 || !ensure_mult_key(mkey)) return false;
+    const double new_scale = rop->scale() / yell::params::P[Li - 1] * c1.scale();
+    std::vector<T> in0(2 * limbs), in1(2 * limbs), out(2 * (Li - 1) * N);
+    pack(in0, 0, rop->bx, Li); pack(in0, limbs, rop->ax, Li); pack(in1, 0, c1.bx, Li); pack(in1, limbs, c1.ax, Li);
+    if (fhe_hip_mul_relin_rescale(ctx(), out.data(), in0.data(), in1.data(), (uint32_t)Li, 1, FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
+    Cipher tmp(Li - 1);
+    std::memcpy(tmp.bx.ptr_at(0), out.data(), (Li - 1) * N * sizeof(T));
+    std::memcpy(tmp.ax.ptr_at(0), out.data() + (Li - 1) * N, (Li - 1) * N * sizeof(T));
+    rop->bx = std::move(tmp.bx); rop->ax = std::move(tmp.ax); rop->mul_aux = nullptr;
+    rop->scale(new_scale);
+    return true;
+  }
+
+  //! The rotation offset is specified in the RotKey (evaluator.cpp:128-136, 299-311, 343-399).
+  bool rotate_slots(Cipher *rop, RotKey const &rkey) const {
+    if (!rop) return false;
+    if (!rop->canonical()) { std::cerr << "Can only rotate canonical ciphertext, call relinearize first." << std::endl; return false; }
+    if (rkey.galois == 0) return true;
+    const size_t Li = rop->moduli_count(), N = context::degree, limbs = Li * N;
+    if (Li > context::nr_ctxt_moduli) throw std::invalid_argument("Too many moduli.");
+    if (Li <= 1) throw std::invalid_argument("nmoduli <= 1");
+    if (!ensure_rot_key(rkey)) return false;
+    std::vector<T> ct(2 * limbs);
+    pack(ct, 0, rop->bx, Li); pack(ct, limbs, rop->ax, Li);
+    if (fhe_hip_rotate(ctx(), rkey.galois, ct.data(), (uint32_t)Li, 1, FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
+    std::memcpy(rop->bx.ptr_at(0), ct.data(), limbs * sizeof(T));
+    std::memcpy(rop->ax.ptr_at(0), ct.data() + limbs, limbs * sizeof(T));
+    return true;
+  }
+
+  //! Rotation with arbitrary offset: binary decomposition over power-of-two keys (evaluator.cpp:184-208)
+  bool rotate_slots(Cipher *rop, int offset, RotKeySet<RotKey> const &rkeys) const {
+    if (!rop) return false;
+    if (!rop->canonical()) { std::cerr << "Can only rotate canonical ciphertext, call relinearize first." << std::endl; return false; }
+    const size_t nr_slots = context::degree >> 1u;
+    bool sign = offset < 0;
+    offset = std::abs(offset) % (int)nr_slots;
+    if (sign) offset = (int)nr_slots - offset;
+    int steps = (int)(std::log2((double)offset) + 1);
+    for (int i = 0; i < steps; ++i) {
+      if (offset & (1 << i)) {
+        auto rotkey = rkeys.get((uint16_t)(1 << i));
+        if (!rotkey) { std::cerr << "No such rotation key for offset " << (1 << i) << "\n"; return false; }
+        rotate_slots(rop, *rotkey);
+      }
+    }
+    return true;
+  }
+};
+}  // namespace fHE

@@ -1,0 +1,215 @@
+// yell/poly.hpp — host-side stand-in for the subset of the `yell` polynomial library that fHE's public API
+// exposes (reference include/fHE/context.hpp:2,21-23; usage listed in SURVEY.md §2 "yell poly").  This is part
+// of the MI355X drop-in (not of the oracle): the transforms forward to the gfx950 NTT through the C-ABI, the
+// pointwise helpers are plain host loops used only by key generation / encryption plumbing.
+// Differences from yell, forced by the north star: the ring degree and the prime table are runtime properties
+// of the active fHE::Context instead of template / compile-time constants.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <iostream>
+#include <memory>
+#include <numeric>
+#include <stdexcept>
+#include <vector>
+
+#include "fhe_hip.h"
+
+namespace yell {
+namespace params {
+using value_type = uint64_t;
+using gt_value_type = unsigned __int128;
+using signed_type = int64_t;
+constexpr size_t kModulusBitsize = 62;
+constexpr size_t kMaxNbModuli = 255;
+// yell::params::P[i]: global prime table of the active context (normal primes first, special primes after)
+struct PrimeTable {
+  const std::vector<value_type> *tbl = nullptr;
+  value_type operator[](size_t i) const { return tbl->at(i); }
+};
+inline PrimeTable P;
+}  // namespace params
+
+// process-wide binding of the yell types to one device context (set by fHE::Context::activate())
+struct runtime {
+  fhe_hip_ctx *ctx = nullptr;
+  size_t degree = 0, logn = 0;
+  static runtime &get() { static runtime r; return r; }
+};
+inline void check(int rc, const char *what) {
+  if (rc != FHE_HIP_OK) throw std::runtime_error(std::string(what) + ": " + fhe_hip_last_error(runtime::get().ctx));
+}
+
+namespace math {
+inline uint64_t reverse_bits(uint64_t x, size_t bits) {
+  uint64_t r = 0;
+  for (size_t i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+  return r;
+}
+inline params::value_type mulmod(params::value_type a, params::value_type b, params::value_type p) {
+  return (params::value_type)(((params::gt_value_type)a * b) % p);
+}
+inline params::value_type powmod(params::value_type a, params::value_type e, params::value_type p) {
+  params::value_type r = 1; a %= p;
+  while (e) { if (e & 1) r = mulmod(r, a, p); a = mulmod(a, a, p); e >>= 1; }
+  return r;
+}
+inline params::value_type inv_mod_prime(params::value_type x, size_t cm) { const auto p = params::P[cm]; return powmod(x % p, p - 2, p); }
+}  // namespace math
+
+namespace ops {
+using T = params::value_type; using gT = params::gt_value_type;
+struct mulmod {
+  T operator()(T x, T y, size_t cm) const { return math::mulmod(x, y, params::P[cm]); }
+  void compute(T &x, T y, size_t cm) const { x = (*this)(x, y, cm); }
+};
+struct addmod {
+  T operator()(T x, T y, size_t cm) const { const T p = params::P[cm]; T s = x % p + y % p; return s >= p ? s - p : s; }
+  void compute(T &x, T y, size_t cm) const { x = (*this)(x, y, cm); }
+};
+struct muladd {  // acc + x*y mod p
+  T operator()(T acc, T x, T y, size_t cm) const { const T p = params::P[cm]; return (T)(((gT)x * y + acc) % p); }
+};
+inline T shoupify(T y, size_t cm) { return (T)(((gT)y << 64) / params::P[cm]); }
+struct mulmod_shoup {
+  T operator()(T x, T y, T yshoup, size_t cm) const {
+    const T p = params::P[cm];
+    T r = x * y - (T)(((gT)x * yshoup) >> 64) * p;
+    return r >= p ? r - p : r;
+  }
+  void compute(T &x, T y, T yshoup, size_t cm) const { x = (*this)(x, y, yshoup, cm); }
+};
+inline void barret_reduction(gT *x, size_t cm) { *x %= params::P[cm]; }
+}  // namespace ops
+
+template <size_t n> struct static_log2 { static constexpr size_t value = 1 + static_log2<n / 2>::value; };
+template <> struct static_log2<1> { static constexpr size_t value = 0; };
+
+// deterministic splitmix64 stream shared by the samplers (the reference's PRNG is not pinned)
+struct prng {
+  uint64_t state;
+  explicit prng(uint64_t seed = 0x243F6A8885A308D3ull) : state(seed) {}
+  uint64_t next() {
+    uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  static prng &global() { static prng g; return g; }
+};
+struct uniform {};
+struct hwt_dist { size_t hwt; explicit hwt_dist(size_t h) : hwt(h) {} };
+struct ZO_dist {};
+// stands for yell::FastGaussianNoise / yell::gaussian: centred binomial of variance 10.5 (sigma ~ 3.24)
+template <class In = uint16_t, class Out = params::value_type, unsigned lu = 2> struct FastGaussianNoise {
+  prng rng;
+  FastGaussianNoise(double /*sigma*/ = 3.2, unsigned /*bits*/ = 128, size_t /*samples*/ = 1 << 14, uint64_t seed = 0x13198A2E03707344ull) : rng(seed) {}
+};
+template <class In = uint16_t, class Out = params::value_type, unsigned lu = 2> struct gaussian {
+  FastGaussianNoise<In, Out, lu> *fg;
+  explicit gaussian(FastGaussianNoise<In, Out, lu> *p) : fg(p) {}
+};
+
+// limb-major polynomial [nmoduli][degree]; limb k lives under the global modulus index k
+class poly {
+  using T = params::value_type;
+  std::vector<T> data_;
+  size_t nmoduli_ = 0;
+
+  void set_small(const std::vector<int> &v) {
+    const size_t N = degree();
+    for (size_t cm = 0; cm < nmoduli_; ++cm) {
+      const T p = params::P[cm];
+      for (size_t d = 0; d < N; ++d) data_[cm * N + d] = v[d] >= 0 ? (T)v[d] : p - (T)(-v[d]);
+    }
+  }
+
+ public:
+  size_t logn;
+  static size_t degree() { return runtime::get().degree; }
+
+  explicit poly(size_t nmoduli = 0) : data_(nmoduli * degree(), 0), nmoduli_(nmoduli), logn(runtime::get().logn) {}
+  template <class Dist> poly(size_t nmoduli, Dist const &dist) : poly(nmoduli) { set(dist); }
+
+  size_t moduli_count() const { return nmoduli_; }
+  T *ptr_at(size_t cm) { return data_.data() + cm * degree(); }
+  const T *cptr_at(size_t cm) const { return data_.data() + cm * degree(); }
+  const T *cptr_end(size_t cm) const { return cptr_at(cm) + degree(); }
+  void resize_moduli_count(size_t n) { data_.resize(n * degree(), 0); nmoduli_ = n; }
+  void clear() { std::fill(data_.begin(), data_.end(), 0); }
+
+  void set(uniform const &) {
+    const size_t N = degree();
+    for (size_t cm = 0; cm < nmoduli_; ++cm) { const T p = params::P[cm]; for (size_t d = 0; d < N; ++d) data_[cm * N + d] = prng::global().next() % p; }
+  }
+  void set(hwt_dist const &h) {
+    const size_t N = degree();
+    std::vector<int> v(N, 0);
+    for (size_t n = 0; n < h.hwt;) { uint64_t r = prng::global().next(); size_t pos = r % N; if (v[pos]) continue; v[pos] = (r >> 63) ? 1 : -1; ++n; }
+    set_small(v);
+  }
+  void set(ZO_dist const &) {
+    std::vector<int> v(degree());
+    for (auto &x : v) { uint64_t r = prng::global().next() >> 62; x = r == 0 ? 1 : (r == 1 ? -1 : 0); }
+    set_small(v);
+  }
+  template <class I, class O, unsigned l> void set(gaussian<I, O, l> const &g) {
+    std::vector<int> v(degree());
+    for (auto &x : v) { uint64_t r = g.fg->rng.next(); x = __builtin_popcountll(r & 0x1FFFFF) - __builtin_popcountll((r >> 21) & 0x1FFFFF); }
+    set_small(v);
+  }
+
+  // yell::poly::forward/backward: every limb, on the GPU through the C-ABI (host buffers are staged by the library)
+  void forward() { transform(false); }
+  void forward_lazy() { transform(false); }  // yell's lazy variant skips the final correction; canonical here
+  void backward() { transform(true); }
+
+  poly &operator+=(poly const &o) {
+    assert(o.nmoduli_ == nmoduli_);
+    ops::addmod add; const size_t N = degree();
+    for (size_t cm = 0; cm < nmoduli_; ++cm) for (size_t d = 0; d < N; ++d) add.compute(data_[cm * N + d], o.data_[cm * N + d], cm);
+    return *this;
+  }
+  poly &operator*=(poly const &o) {
+    assert(o.nmoduli_ >= nmoduli_);
+    ops::mulmod mul; const size_t N = degree();
+    for (size_t cm = 0; cm < nmoduli_; ++cm) for (size_t d = 0; d < N; ++d) mul.compute(data_[cm * N + d], o.data_[cm * N + d], cm);
+    return *this;
+  }
+  void add_product_of(poly const &a, poly const &b) {  // *this += a * b (pointwise)
+    ops::muladd ma; const size_t N = degree();
+    for (size_t cm = 0; cm < nmoduli_; ++cm) for (size_t d = 0; d < N; ++d) data_[cm * N + d] = ma(data_[cm * N + d], a.cptr_at(cm)[d], b.cptr_at(cm)[d], cm);
+  }
+  void negate() {
+    const size_t N = degree();
+    for (size_t cm = 0; cm < nmoduli_; ++cm) { const T p = params::P[cm]; for (size_t d = 0; d < N; ++d) { T &x = data_[cm * N + d]; x = x ? p - x % p : 0; } }
+  }
+
+ private:
+  void transform(bool inverse) {
+    if (!nmoduli_) return;
+    std::vector<uint32_t> idx(nmoduli_);
+    std::iota(idx.begin(), idx.end(), 0u);
+    auto &rt = runtime::get();
+    check(inverse ? fhe_hip_ntt_backward(rt.ctx, data_.data(), idx.data(), nmoduli_, FHE_HIP_MEM_HOST)
+                  : fhe_hip_ntt_forward(rt.ctx, data_.data(), idx.data(), nmoduli_, FHE_HIP_MEM_HOST), "ntt");
+  }
+};
+
+// yell::ntt<N>::forward/backward(T*, moduli_idx) — the raw-pointer seam used all over evaluator.cpp / base_converter.cpp
+struct ntt {
+  static void forward(params::value_type *limb, size_t moduli_idx) {
+    uint32_t m = (uint32_t)moduli_idx;
+    check(fhe_hip_ntt_forward(runtime::get().ctx, limb, &m, 1, FHE_HIP_MEM_HOST), "ntt::forward");
+  }
+  static void backward(params::value_type *limb, size_t moduli_idx) {
+    uint32_t m = (uint32_t)moduli_idx;
+    check(fhe_hip_ntt_backward(runtime::get().ctx, limb, &m, 1, FHE_HIP_MEM_HOST), "ntt::backward");
+  }
+};
+}  // namespace yell

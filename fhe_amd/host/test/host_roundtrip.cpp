@@ -1,0 +1,105 @@
+// host_roundtrip — BASELINE config 1 through the C++ host mirror: keygen -> encrypt -> multiply_and_relin
+// (one fused GPU call) -> decrypt, plus a rotation.  Mirrors what the reference's main.cpp does with its own API.
+// Writes every key, input and output limb to a dump file so that tests/ can re-run the same inputs through the CPU
+// oracle and compare bit for bit.   usage: host_roundtrip <logN> <L> <K> <dump-file>
+#include <cstdio>
+#include <cstdlib>
+#include "fHE/context.hpp"
+#include "fHE/cipher.hpp"
+#include "fHE/decryptor.hpp"
+#include "fHE/encryptor.hpp"
+#include "fHE/evaluator.hpp"
+
+using T = yell::params::value_type;
+static void dump(FILE *f, const char *name, fHE::context::poly_t const &p) {
+  uint64_t n = p.moduli_count();
+  char tag[16] = {0};
+  std::snprintf(tag, sizeof(tag), "%s", name);
+  std::fwrite(tag, 1, 16, f);
+  std::fwrite(&n, 8, 1, f);
+  std::fwrite(p.cptr_at(0), 8, n * fHE::context::degree, f);
+}
+
+int main(int argc, char **argv) {
+  const uint32_t logN = argc > 1 ? std::atoi(argv[1]) : 13, L = argc > 2 ? std::atoi(argv[2]) : 4, K = argc > 3 ? std::atoi(argv[3]) : 4;
+  const char *path = argc > 4 ? argv[4] : "host_roundtrip.bin";
+  try {
+    fHE::Context context(logN, L, K, 0);
+    const size_t N = fHE::context::degree;
+    fHE::SK sk;
+    fHE::PK pk(sk);
+    fHE::MultKey mkey(sk);
+    fHE::RotKey rkey(sk, 1, fHE::RotKey::Direction::LEFT);
+    fHE::Encryptor encryptor;
+    fHE::Decryptor decryptor;
+    fHE::Evaluator evaluator;
+
+    // integer plaintexts a, b with small coefficients times 2^40
+    fHE::context::poly_t ma(L), mb(L);
+    std::vector<long> a(N), b(N);
+    yell::prng rng(42);
+    for (size_t d = 0; d < N; ++d) { a[d] = (long)(rng.next() % 9) - 4; b[d] = (long)(rng.next() % 9) - 4; }
+    for (size_t cm = 0; cm < L; ++cm) {
+      const T p = yell::params::P[cm];
+      for (size_t d = 0; d < N; ++d) {
+        const T sa = (T)std::labs(a[d]) << 40, sb = (T)std::labs(b[d]) << 40;
+        ma.ptr_at(cm)[d] = a[d] >= 0 ? sa : p - sa;
+        mb.ptr_at(cm)[d] = b[d] >= 0 ? sb : p - sb;
+      }
+    }
+    fHE::Cipher ca, cb;
+    encryptor.encrypt(&ca, ma, pk);
+    encryptor.encrypt(&cb, mb, pk);
+    ca.scale(1099511627776.0); cb.scale(1099511627776.0);
+    fHE::Cipher in_a(ca), in_b(cb);
+
+    // fresh decrypt: message + small noise
+    fHE::context::poly_t dec(L);
+    decryptor.decrypt(&dec, ca, sk);
+    long worst = 0;
+    for (size_t d = 0; d < N; ++d) {
+      const T p = yell::params::P[0]; T v = dec.cptr_at(0)[d];
+      long c = v > p / 2 ? -(long)(p - v) : (long)v;
+      worst = std::max(worst, std::labs(c - (a[d] << 40)));
+    }
+    std::printf("fresh decrypt noise (limb 0): %ld\n", worst);
+    if (worst > (1L << 20)) { std::fprintf(stderr, "decrypt noise too large\n"); return 2; }
+
+    if (!evaluator.multiply_and_relin(&ca, cb, mkey)) { std::fprintf(stderr, "multiply_and_relin failed\n"); return 3; }
+    if (ca.moduli_count() != L - 1 || !ca.canonical()) { std::fprintf(stderr, "unexpected result shape\n"); return 4; }
+    fHE::context::poly_t dec_mul(L - 1);
+    decryptor.decrypt(&dec_mul, ca, sk);
+
+    // separate multiply + relinearize must give the same ciphertext (evaluator.cpp:119-126)
+    fHE::Cipher two_step(in_a);
+    if (!evaluator.multiply(&two_step, in_b) || two_step.canonical() || !evaluator.relinearize(&two_step, mkey)) { std::fprintf(stderr, "two-step path failed\n"); return 5; }
+    if (std::memcmp(two_step.bx.cptr_at(0), ca.bx.cptr_at(0), (L - 1) * N * 8) || std::memcmp(two_step.ax.cptr_at(0), ca.ax.cptr_at(0), (L - 1) * N * 8)) {
+      std::fprintf(stderr, "multiply+relinearize differs from multiply_and_relin\n"); return 6;
+    }
+    // misuse conventions: relinearize on a canonical ciphertext returns false; rotate of a non-canonical one too
+    if (evaluator.relinearize(&ca, mkey)) { std::fprintf(stderr, "relinearize accepted a canonical ciphertext\n"); return 7; }
+
+    fHE::Cipher rot(in_a);
+    if (!evaluator.rotate_slots(&rot, rkey)) { std::fprintf(stderr, "rotate_slots failed\n"); return 8; }
+    fHE::context::poly_t dec_rot(L);
+    decryptor.decrypt(&dec_rot, rot, sk);
+
+    FILE *f = std::fopen(path, "wb");
+    if (!f) { std::perror("fopen"); return 9; }
+    uint64_t hdr[4] = {logN, L, K, rkey.galois};
+    std::fwrite(hdr, 8, 4, f);
+    dump(f, "sx", sk.sx); dump(f, "ext_sx", sk.ext_sx);
+    for (size_t j = 0; j < L; ++j) { dump(f, "mk_beta", *mkey.get_beta_at(j)); dump(f, "mk_alpha", *mkey.get_alpha_at(j)); }
+    dump(f, "rk_beta", rkey.beta); dump(f, "rk_alpha", rkey.alpha);
+    dump(f, "a_bx", in_a.bx); dump(f, "a_ax", in_a.ax); dump(f, "b_bx", in_b.bx); dump(f, "b_ax", in_b.ax);
+    dump(f, "mul_bx", ca.bx); dump(f, "mul_ax", ca.ax); dump(f, "dec_mul", dec_mul);
+    dump(f, "rot_bx", rot.bx); dump(f, "rot_ax", rot.ax); dump(f, "dec_rot", dec_rot);
+    dump(f, "msg_a", ma); dump(f, "msg_b", mb);
+    std::fclose(f);
+    std::printf("host_roundtrip OK\n");
+    return 0;
+  } catch (std::exception const &e) {
+    std::fprintf(stderr, "exception: %s\n", e.what());
+    return 1;
+  }
+}

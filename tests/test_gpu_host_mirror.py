@@ -1,0 +1,65 @@
+"""C++ host mirror (fhe_amd/host: fHE::Context / Encryptor / Evaluator / Decryptor over the C-ABI), BASELINE config 1:
+the driver runs keygen -> encrypt -> multiply_and_relin -> decrypt and a rotation on the GPU and dumps every key,
+input and output; the same keys and inputs then go through the CPU oracle and must match bit for bit at the
+ciphertext-limb and decrypted-plaintext level."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "fhe_amd", "host", "bin", "host_roundtrip")
+
+
+def test_host_mirror_driver_is_built():
+    assert os.path.exists(BIN), "run __graft_entry__.build() (make -C fhe_amd/host)"
+
+
+def _load_dump(path, N):
+    raw = open(path, "rb").read()
+    hdr = struct.unpack("<4Q", raw[:32])
+    off, out = 32, {}
+    while off < len(raw):
+        tag = raw[off:off + 16].split(b"\0")[0].decode()
+        n = struct.unpack("<Q", raw[off + 16:off + 24])[0]
+        arr = np.frombuffer(raw, dtype=np.uint64, count=n * N, offset=off + 24).reshape(n, N).copy()
+        out.setdefault(tag, []).append(arr)
+        off += 24 + 8 * n * N
+    return hdr, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("logN,L,K", [(13, 4, 4), (12, 3, 2)])
+def test_config1_roundtrip_through_cpp_api(tmp_path, logN, L, K):
+    path = str(tmp_path / "dump.bin")
+    r = subprocess.run([BIN, str(logN), str(L), str(K), path], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "host_roundtrip OK" in r.stdout
+    N = 1 << logN
+    hdr, d = _load_dump(path, N)
+    assert hdr[:3] == (logN, L, K)
+    galois = hdr[3]
+    o = orc.Oracle(logN, L, K)  # same prime-table rule as fHE::Context::default_primes
+    sx, ext = d["sx"][0], d["ext_sx"][0]
+    beta, alpha = np.stack(d["mk_beta"]), np.stack(d["mk_alpha"])
+    a_bx, a_ax, b_bx, b_ax = d["a_bx"][0], d["a_ax"][0], d["b_bx"][0], d["b_ax"][0]
+    # ciphertext-limb level
+    ob, oa = o.mul_relin_rescale(a_bx, a_ax, b_bx, b_ax, beta, alpha)
+    assert np.array_equal(d["mul_bx"][0], ob) and np.array_equal(d["mul_ax"][0], oa)
+    # decrypted-plaintext level
+    assert np.array_equal(d["dec_mul"][0], o.decrypt(ob, oa, sx))
+    rb, ra = o.rotate(a_bx, a_ax, galois, d["rk_beta"][0], d["rk_alpha"][0])
+    assert galois == o.rotation_galois(1)
+    assert np.array_equal(d["rot_bx"][0], rb) and np.array_equal(d["rot_ax"][0], ra)
+    assert np.array_equal(d["dec_rot"][0], o.decrypt(rb, ra, sx))
+    # the keys the C++ side generated are valid: decrypt(rot) is the rotated message up to noise on limb 0
+    p0 = int(o.primes[0])
+    msg = d["msg_a"][0][0]
+    want = o.apply_galois_non_ntt(d["msg_a"][0].copy(), galois)[0]
+    diff = (d["dec_rot"][0][0].astype(object) - want.astype(object)) % p0
+    diff = np.minimum(diff, p0 - diff)
+    assert int(diff.max()) < 1 << 30 and msg.any()
