@@ -1,6 +1,6 @@
 // yell/poly.hpp — host-side stand-in for the subset of the `yell` polynomial library that fHE's public API
 // exposes (reference include/fHE/context.hpp:2,21-23; usage listed in SURVEY.md §2 "yell poly").  This is part
-// of the MI355X drop-in (not of the oracle): the transforms forward to the gfx950 NTT through the C-ABI, the
+// of the MI355X drop-in product: the transforms forward to the gfx950 NTT through the C-ABI, the
 // pointwise helpers are plain host loops used only by key generation / encryption plumbing.
 // Differences from yell, forced by the north star: the ring degree and the prime table are runtime properties
 // of the active fHE::Context instead of template / compile-time constants.

@@ -1,7 +1,7 @@
 // host_roundtrip — BASELINE config 1 through the C++ host mirror: keygen -> encrypt -> multiply_and_relin
 // (one fused GPU call) -> decrypt, plus a rotation.  Mirrors what the reference's main.cpp does with its own API.
 // Writes every key, input and output limb to a dump file so that tests/ can re-run the same inputs through the CPU
-// oracle and compare bit for bit.   usage: host_roundtrip <logN> <L> <K> <dump-file>
+// checker and compare bit for bit.   usage: host_roundtrip <logN> <L> <K> <dump-file>
 #include <cstdio>
 #include <cstdlib>
 #include "fHE/context.hpp"
