@@ -1,0 +1,140 @@
+"""Batching layer (north_star subsystem 4): shard independent ciphertext operations over the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on GPUs, "gloo" in the CPU tests).  Nothing in
+fHE's path couples different ciphertexts, so the data path needs NO collective: ranks work on disjoint,
+contiguous slices of the batch with keys and tables replicated.  RCCL is used only either side of the path, for callers
+whose data starts on one rank: a star scatter of inputs from the root (grouped point-to-point sends, so all xGMI links of
+the root carry traffic concurrently), a broadcast of key material once, and the mirror-image gather of results.
+The reference has no counterpart (it is single-process, single-thread).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items, world, rank):
+    """Contiguous split [lo, hi) of n_items over `world` ranks; the first n_items % world ranks get one more."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class ShardedBatch:
+    """Scatter / compute / gather of a batch whose leading dimension indexes independent ciphertexts."""
+
+    def __init__(self, group=None, root=0, device=None):
+        self.group = group
+        self.root = root
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.device = device
+
+    def bounds(self, n_items, rank=None):
+        return shard_bounds(n_items, self.world, self.rank if rank is None else rank)
+
+    def _p2p(self, ops):
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+    def scatter(self, full, n_items, item_shape, dtype=torch.int64):
+        """Root holds `full` = [n_items, *item_shape]; every rank returns its slice [hi-lo, *item_shape]."""
+        lo, hi = self.bounds(n_items)
+        if self.world == 1:
+            return full[lo:hi]
+        if self.rank == self.root:
+            ops = []
+            for r in range(self.world):
+                if r == self.root:
+                    continue
+                rlo, rhi = self.bounds(n_items, r)
+                if rhi > rlo:
+                    ops.append(dist.P2POp(dist.isend, full[rlo:rhi].contiguous(), r, self.group))
+            self._p2p(ops)
+            return full[lo:hi]
+        local = torch.empty((hi - lo,) + tuple(item_shape), dtype=dtype, device=self.device)
+        if hi > lo:
+            self._p2p([dist.P2POp(dist.irecv, local, self.root, self.group)])
+        return local
+
+    def gather(self, local, n_items, item_shape, dtype=torch.int64):
+        """Mirror of scatter: the root returns [n_items, *item_shape], other ranks None."""
+        lo, hi = self.bounds(n_items)
+        if self.world == 1:
+            return local
+        if self.rank == self.root:
+            full = torch.empty((n_items,) + tuple(item_shape), dtype=dtype, device=self.device)
+            full[lo:hi] = local
+            ops = []
+            for r in range(self.world):
+                if r == self.root:
+                    continue
+                rlo, rhi = self.bounds(n_items, r)
+                if rhi > rlo:
+                    ops.append(dist.P2POp(dist.irecv, full[rlo:rhi], r, self.group))
+            self._p2p(ops)
+            return full
+        if hi > lo:
+            self._p2p([dist.P2POp(dist.isend, local.contiguous(), self.root, self.group)])
+        return None
+
+    def broadcast(self, tensor):
+        """Key material: once, from the root to every rank."""
+        if self.world > 1:
+            dist.broadcast(tensor, self.root, group=self.group)
+        return tensor
+
+    def run(self, compute, inputs, n_items, in_shapes, out_shape, chunk=None):
+        """inputs: list of root-resident tensors (None on other ranks); compute(local_inputs, n_local) -> local output.
+        With `chunk`, the scatter / compute / gather proceeds in chunks of that many items per rank so that a batch
+        larger than one GPU's memory can stream through."""
+        outs = []
+        step = max(1, n_items if not chunk else chunk * self.world)
+        for c0 in range(0, max(n_items, 1), step):
+            n = min(step, n_items - c0)
+            local_in = [self.scatter(None if x is None else x[c0:c0 + n], n, shp) for x, shp in zip(inputs, in_shapes)]
+            lo, hi = self.bounds(n)
+            local_out = compute(local_in, hi - lo)
+            outs.append(self.gather(local_out, n, out_shape))
+        if self.rank != self.root:
+            return None
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+
+class ShardedEvaluator:
+    """Evaluator::multiply_and_relin / rotate_slots over a sharded batch: each rank owns one HipContext."""
+
+    def __init__(self, ctx, group=None, root=0):
+        self.ctx = ctx
+        self.N = ctx.N
+        self.batch = ShardedBatch(group, root, device=torch.device("cuda", ctx.device))
+
+    def load_mult_key(self, beta, alpha):
+        L, N = self.ctx.L, self.N
+        if beta is None:
+            beta = torch.empty((L, L, N), dtype=torch.int64, device=self.batch.device)
+            alpha = torch.empty_like(beta)
+        self.batch.broadcast(beta)
+        self.batch.broadcast(alpha)
+        self.ctx.load_mult_key(beta, alpha)
+
+    def mul_relin_rescale(self, c0, c1, n_items, Li, chunk=None):
+        N = self.N
+
+        def compute(local, n):
+            out = torch.empty((n, 2, Li - 1, N), dtype=torch.int64, device=self.batch.device)
+            if n:
+                self.ctx.mul_relin_rescale(out, local[0].contiguous(), local[1].contiguous(), Li, batch=n)
+            return out
+
+        return self.batch.run(compute, [c0, c1], n_items, [(2, Li, N)] * 2, (2, Li - 1, N), chunk)
+
+    def rotate(self, galois, ct, n_items, Li, chunk=None):
+        N = self.N
+
+        def compute(local, n):
+            work = local[0].contiguous().clone()
+            if n:
+                self.ctx.rotate(galois, work, Li, batch=n)
+            return work
+
+        return self.batch.run(compute, [ct], n_items, [(2, Li, N)], (2, Li, N), chunk)
