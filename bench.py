@@ -27,7 +27,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 WORKLOADS = {
     #        logN  L   K   Li  default batch
-    "c3": (16, 30, 1, 30, 4),
+    "c3": (16, 30, 1, 30, 8),
     "c5": (15, 16, 1, 16, 16),
     "c4": (16, 30, 30, 30, 4),
     "ntt": (16, 8, 0, 8, 512),

@@ -281,9 +281,9 @@ int dev_conv_to_special(fhe_hip_ctx *c, u64 *rop, u32 rop_limbs, u32 rop_off, co
   a.hat_m = c->d_hat_qj_pi_m + (size_t)(Li - 2) * c->K * c->L;
   a.primes = c->d_primes;
   a.nsrc = Li; a.src_first = 0; a.src_limbs = op_limbs; a.src_off = 0;
-  a.tgt_first = c->L; a.out_limbs = rop_limbs; a.out_off = rop_off; a.hat_stride = c->L;
+  a.tgt_first = c->L; a.out_limbs = rop_limbs; a.out_off = rop_off; a.hat_stride = c->L; a.ntgt = c->K;
   a.N = c->N;
-  LAUNCH_SP(c, "bconv_modup", bconv_kernel, pw_grid(c, c->K, batch), dim3(PW_THREADS), a);
+  LAUNCH_SP(c, "bconv_modup", bconv_kernel, dim3((unsigned)(c->N / PW_THREADS), (c->K + BCONV_TC - 1) / BCONV_TC, batch), dim3(PW_THREADS), a);
   return FHE_HIP_OK;
 }
 // neg_approx_convert_to_normal_basis for j < L0: special limbs (power basis) at limb offset sp_off of op
@@ -294,9 +294,9 @@ int dev_conv_to_normal(fhe_hip_ctx *c, u64 *rop, u32 L0, const u64 *op, u32 op_l
   a.hat_m = c->d_neg_hat_pi_qj_m;
   a.primes = c->d_primes;
   a.nsrc = c->K; a.src_first = c->L; a.src_limbs = op_limbs; a.src_off = sp_off;
-  a.tgt_first = 0; a.out_limbs = L0; a.out_off = 0; a.hat_stride = c->K;
+  a.tgt_first = 0; a.out_limbs = L0; a.out_off = 0; a.hat_stride = c->K; a.ntgt = L0;
   a.N = c->N;
-  LAUNCH_SP(c, "bconv_moddown", bconv_kernel, pw_grid(c, L0, batch), dim3(PW_THREADS), a);
+  LAUNCH_SP(c, "bconv_moddown", bconv_kernel, dim3((unsigned)(c->N / PW_THREADS), (L0 + BCONV_TC - 1) / BCONV_TC, batch), dim3(PW_THREADS), a);
   return FHE_HIP_OK;
 }
 
@@ -329,9 +329,9 @@ int dev_rescale(fhe_hip_ctx *c, u64 *rop, const u64 *op, u32 n, u32 entries, int
 int dev_relin(fhe_hip_ctx *c, u64 *out, const u64 *ct3, u32 Li, u32 batch) {
   const u64 N = c->N;
   if (!c->d_mk_beta) FAIL(c, FHE_HIP_ERR_NOKEY, "mult key not loaded");
-  // bound the Li^2 intermediate: process the batch in chunks of at most ~2 GiB
+  // bound the Li^2 intermediate: process the batch in chunks of at most 8 GiB
   const size_t per_ct = (size_t)Li * Li * N * 8;
-  u32 chunk = (u32)((2ull << 30) / per_ct);
+  u32 chunk = (u32)((8ull << 30) / per_ct);
   if (chunk < 1) chunk = 1;
   if (chunk > batch) chunk = batch;
   TRY(ensure_ws(c, 0, (size_t)chunk * Li * N * 8));
@@ -353,7 +353,7 @@ int dev_relin(fhe_hip_ctx *c, u64 *out, const u64 *ct3, u32 Li, u32 batch) {
     ra.beta_m = c->d_mk_beta; ra.alpha_m = c->d_mk_alpha; ra.tw = c->d_tw_fwd; ra.primes = c->d_primes;
     ra.Li = Li; ra.L = c->L; ra.logN = c->logN; ra.logR = c->logR; ra.i0 = 0;
     const u32 R = 1u << c->logR, rows = R < 16 ? R : 16;
-    LAUNCH_SP(c, "relin_rows_mac", relin_rows_mac_kernel, dim3(R / rows, Li, nb), dim3(16 * rows), ra);
+    LAUNCH_SP(c, "relin_rows_mac", relin_rows_mac_kernel, dim3(nb, R / rows, Li), dim3(16 * rows), ra);
   }
   return FHE_HIP_OK;
 }

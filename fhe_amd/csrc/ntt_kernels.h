@@ -273,8 +273,9 @@ __global__ __launch_bounds__(256) void relin_rows_mac_kernel(RelinArgs a) {
   __shared__ __attribute__((aligned(16))) u64 lds[16 * ROW_LDS];
   const u32 tid = threadIdx.x, rloc = tid >> 4, t = tid & 15;
   const u32 rows_per_wg = blockDim.x >> 4;
-  const u32 row = blockIdx.x * rows_per_wg + rloc;
-  const u32 i = blockIdx.y + a.i0, b = blockIdx.z;
+  // grid = (batch, row blocks, limbs): the ciphertexts of a batch that share key rows are dispatched back to back
+  const u32 row = blockIdx.y * rows_per_wg + rloc;
+  const u32 i = blockIdx.z + a.i0, b = blockIdx.x;
   const u32 Li = a.Li;
   const PrimeC P = a.primes[i];
   const u64 N = 1ull << a.logN;

@@ -87,27 +87,43 @@ struct BconvArgs {
   const u64 *hat_m;   // [ntgt][hat_stride]  Montgomery form w.r.t. the target prime
   const PrimeC *primes;
   u32 nsrc, src_first, src_limbs, src_off;
-  u32 tgt_first, out_limbs, out_off, hat_stride;
+  u32 tgt_first, out_limbs, out_off, hat_stride, ntgt;
   u64 N;
 };
+// One thread = one coefficient x BCONV_TC targets.  Per source limb k the canonical digit t0 = [x_k * inv_k]_{p_k}
+// is computed once and multiplied into BCONV_TC lazy 128-bit accumulators (4 v_mad_u64_u32 + a carry chain per term,
+// no reduction); every 8 terms the accumulators are folded with one Montgomery reduction (hat is in Montgomery
+// form, so the fold yields sum t0*hat mod p directly; 8 terms keep thi < 2^63 so thi - w + p cannot wrap).
+#define BCONV_TC 8
 template <bool SP>
 __global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
-  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
-  const u32 t = blockIdx.y, e = blockIdx.z;
-  const PrimeC PT = a.primes[a.tgt_first + t];
+  const u64 d = (u64)blockIdx.x * PW_THREADS + threadIdx.x;
+  const u32 tbase = blockIdx.y * BCONV_TC, e = blockIdx.z;
+  const u32 ntgt = a.ntgt;
   const u64 *sp = a.src + ((u64)e * a.src_limbs + a.src_off) * a.N + d;
-  const u64 *hat = a.hat_m + (u64)t * a.hat_stride;
-  u64 acc[2] = {0, 0};
-  for (u32 k = 0; k < a.nsrc; ++k) {
-    const PrimeC PS = a.primes[a.src_first + k];
-    const ulonglong2 x = ld2(sp + (u64)k * a.N);
-    const u64 inv = a.inv_m[k], h = hat[k];
-    const u64 t0 = csub(mont_mul<SP>(inv, x.x, PS), PS.p);  // canonical residue mod the source prime
-    const u64 t1 = csub(mont_mul<SP>(inv, x.y, PS), PS.p);
-    acc[0] = csub(acc[0] + mont_mul<SP>(h, t0, PT), PT.twop);
-    acc[1] = csub(acc[1] + mont_mul<SP>(h, t1, PT), PT.twop);
+  u64 hi[BCONV_TC], lo[BCONV_TC], ps[BCONV_TC];
+  u32 tt[BCONV_TC];
+#pragma unroll
+  for (int t = 0; t < BCONV_TC; ++t) { hi[t] = 0; lo[t] = 0; ps[t] = 0; tt[t] = (tbase + t < ntgt) ? tbase + t : ntgt - 1; }
+  for (u32 k0 = 0; k0 < a.nsrc; k0 += 8) {
+    const u32 kend = (k0 + 8 < a.nsrc) ? k0 + 8 : a.nsrc;
+    for (u32 k = k0; k < kend; ++k) {
+      const PrimeC PS = a.primes[a.src_first + k];
+      const u64 t0 = csub(mont_mul<SP>(a.inv_m[k], sp[(u64)k * a.N], PS), PS.p);  // canonical residue mod the source prime
+#pragma unroll
+      for (int t = 0; t < BCONV_TC; ++t) mac128(hi[t], lo[t], a.hat_m[(u64)tt[t] * a.hat_stride + k], t0);
+    }
+#pragma unroll
+    for (int t = 0; t < BCONV_TC; ++t) {
+      const PrimeC PT = a.primes[a.tgt_first + tt[t]];
+      const u64 r = csub(csub(mont_reduce<SP>(hi[t], lo[t], PT), PT.twop), PT.p);  // (0,3p) -> [0,p)
+      ps[t] = csub(ps[t] + r, PT.p);
+      hi[t] = 0; lo[t] = 0;
+    }
   }
-  st2(a.out + ((u64)e * a.out_limbs + a.out_off + t) * a.N + d, csub(acc[0], PT.p), csub(acc[1], PT.p));
+#pragma unroll
+  for (int t = 0; t < BCONV_TC; ++t)
+    if (tbase + t < ntgt) a.out[((u64)e * a.out_limbs + a.out_off + tbase + t) * a.N + d] = ps[t];
 }
 
 // tail of approximated_mod_down (src/base_converter.cpp:227-240): out_j = (src_j + conv_j) * P^-1 mod q_j,
