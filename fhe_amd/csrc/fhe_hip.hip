@@ -353,7 +353,8 @@ int dev_relin(fhe_hip_ctx *c, u64 *out, const u64 *ct3, u32 Li, u32 batch) {
     ra.beta_m = c->d_mk_beta; ra.alpha_m = c->d_mk_alpha; ra.tw = c->d_tw_fwd; ra.primes = c->d_primes;
     ra.Li = Li; ra.L = c->L; ra.logN = c->logN; ra.logR = c->logR; ra.i0 = 0;
     const u32 R = 1u << c->logR, rows = R < 16 ? R : 16;
-    LAUNCH_SP(c, "relin_rows_mac", relin_rows_mac_kernel, dim3(nb, R / rows, Li), dim3(16 * rows), ra);
+    ra.nb = nb; ra.rb_count = R / rows;
+    LAUNCH_SP(c, "relin_rows_mac", relin_rows_mac_kernel, dim3(nb * (R / rows) * Li), dim3(16 * rows), ra);
   }
   return FHE_HIP_OK;
 }

@@ -266,6 +266,7 @@ struct RelinArgs {
   const u64 *beta_m, *alpha_m;
   const u64 *tw; const PrimeC *primes;
   u32 Li, L, logN, logR, i0;
+  u32 nb, rb_count;  // batch entries and row blocks per limb (grid decode)
 };
 
 template <bool SP>
@@ -273,9 +274,27 @@ __global__ __launch_bounds__(256) void relin_rows_mac_kernel(RelinArgs a) {
   __shared__ __attribute__((aligned(16))) u64 lds[16 * ROW_LDS];
   const u32 tid = threadIdx.x, rloc = tid >> 4, t = tid & 15;
   const u32 rows_per_wg = blockDim.x >> 4;
-  // grid = (batch, row blocks, limbs): the ciphertexts of a batch that share key rows are dispatched back to back
-  const u32 row = blockIdx.y * rows_per_wg + rloc;
-  const u32 i = blockIdx.z + a.i0, b = blockIdx.x;
+  // 1-D grid over (limb i, row block rb, ciphertext b).  Workgroups are dealt round-robin over the 8 XCDs, each with a
+  // private L2: ids that are equal mod 8 share an XCD, so the id is decoded as xcd = id % 8 (low bits of rb), then b
+  // fastest: the ciphertexts of a batch that read the same key rows and twiddles (same i, rb) run back to back on ONE
+  // XCD and share them through its L2 (speed only; any placement is correct).
+  u32 rb, b, i;
+  {
+    const u32 id = blockIdx.x, nb = a.nb, RB = a.rb_count;
+    if ((RB & 7) == 0) {
+      const u32 xcd = id & 7, m = id >> 3;
+      b = m % nb;
+      const u32 rest = m / nb;
+      rb = xcd + 8 * (rest % (RB >> 3));
+      i = rest / (RB >> 3);
+    } else {
+      b = id % nb;
+      rb = (id / nb) % RB;
+      i = id / (nb * RB);
+    }
+    i += a.i0;
+  }
+  const u32 row = rb * rows_per_wg + rloc;
   const u32 Li = a.Li;
   const PrimeC P = a.primes[i];
   const u64 N = 1ull << a.logN;
