@@ -21,6 +21,10 @@ struct RotKeyDev {
   u64 *beta_m = nullptr, *alpha_m = nullptr;  // [(L+K)][N], Montgomery form
 };
 
+struct MixedRotKeyDev {
+  u64 *beta_m = nullptr, *alpha_m = nullptr;  // [L][L+1][N], Montgomery form
+};
+
 struct ProfEntry {
   std::string name;
   uint64_t launches = 0;
@@ -52,6 +56,7 @@ struct fhe_hip_ctx {
   // keys
   u64 *d_mk_beta = nullptr, *d_mk_alpha = nullptr;  // [L][L][N] Montgomery form
   std::map<u64, RotKeyDev> rot_keys;
+  std::map<u64, MixedRotKeyDev> mixed_keys;
   std::map<u64, u32 *> galois_perm;
   // workspaces (grow-only)
   void *ws[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -349,9 +354,12 @@ int dev_relin(fhe_hip_ctx *c, u64 *out, const u64 *ct3, u32 Li, u32 batch) {
     pf.skip_diag = Li; pf.cols_only = true;
     TRY(ntt_run(c, pf, false));
     RelinArgs ra;
-    ra.t1 = t; ra.ct3 = in; ra.out = out + (size_t)b0 * 2 * Li * N;
-    ra.beta_m = c->d_mk_beta; ra.alpha_m = c->d_mk_alpha; ra.tw = c->d_tw_fwd; ra.primes = c->d_primes;
-    ra.Li = Li; ra.L = c->L; ra.logN = c->logN; ra.logR = c->logR; ra.i0 = 0;
+    ra.t1 = t; ra.out = out + (size_t)b0 * 2 * Li * N;
+    ra.diag = in + (size_t)2 * Li * N; ra.diag_bstride = (u64)3 * Li * N;            // ct[2] limb i (j == i)
+    ra.add0 = in; ra.add1 = in + (size_t)Li * N; ra.add_bstride = (u64)3 * Li * N;   // + ct[0], + ct[1]
+    ra.beta_m = c->d_mk_beta; ra.alpha_m = c->d_mk_alpha; ra.klimbs = c->L;
+    ra.tw = c->d_tw_fwd; ra.primes = c->d_primes; ra.omap = c->d_iota;
+    ra.nd = Li; ra.nout = Li; ra.logN = c->logN; ra.logR = c->logR;
     const u32 R = 1u << c->logR, rows = R < 16 ? R : 16;
     ra.nb = nb; ra.rb_count = R / rows;
     LAUNCH_SP(c, "relin_rows_mac", relin_rows_mac_kernel, dim3(nb * (R / rows) * Li), dim3(16 * rows), ra);
@@ -454,6 +462,58 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch) {
   return FHE_HIP_OK;
 }
 
+// rotate_slots_inplace(MixedRotKey) + apply_rotation_key(MixedRotKey) (evaluator.cpp:313-325, 403-516); ct in place
+int dev_rotate_mixed(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch) {
+  const u64 N = c->N; const u32 nout = Li + 1;
+  auto it = c->mixed_keys.find(galois);
+  if (it == c->mixed_keys.end()) FAIL(c, FHE_HIP_ERR_NOKEY, "mixed rotation key not loaded for this galois element");
+  const size_t ctb = (size_t)batch * 2 * Li * N * 8;
+  TRY(ensure_ws(c, 3, ctb));                                       // g = galois(ct)
+  TRY(ensure_ws(c, 0, (size_t)batch * Li * N * 8));                // power basis of the digits
+  TRY(ensure_ws(c, 1, (size_t)batch * nout * Li * N * 8));         // t1
+  TRY(ensure_ws(c, 4, (size_t)batch * 2 * nout * N * 8));          // ans_bx / ans_ax over Li+1 limbs
+  u64 *g = (u64 *)c->ws[3], *pw = (u64 *)c->ws[0], *t = (u64 *)c->ws[1], *ans = (u64 *)c->ws[4];
+  if (galois == 1) {
+    HIPCHK(c, hipMemcpyAsync(g, ct, ctb, hipMemcpyDeviceToDevice, c->stream));
+  } else {
+    u32 *perm = nullptr;
+    TRY(get_galois_perm(c, galois, &perm));
+    LAUNCH(c, "galois_gather", galois_gather_kernel, dim3((unsigned)(N / PW_THREADS), 2 * Li, batch), dim3(PW_THREADS), g, (const u64 *)ct,
+           (const u32 *)perm, N);
+  }
+  // [ct_1]_qi -> power basis (:425-427)
+  NttPlan pi{g + (size_t)Li * N, pw, c->d_iota, 1, Li, Li, Li, batch, (u64)2 * Li * N, (u64)Li * N};
+  TRY(ntt_run(c, pi, true));
+  // column pass of NTT_{j}(digit i) for the Li+1 targets (limb id = j*Li + i), diagonal skipped (:436-437)
+  const u32 *omap = c->d_rotmap + (size_t)Li * c->M;   // j < Li ? j : L
+  NttPlan pf{pw, t, omap, Li, nout, Li, nout * Li, batch, (u64)Li * N, (u64)nout * Li * N};
+  pf.skip_diag = Li; pf.cols_only = true;
+  TRY(ntt_run(c, pf, false));
+  RelinArgs ra;
+  ra.t1 = t; ra.out = ans;
+  ra.diag = g + (size_t)Li * N; ra.diag_bstride = (u64)2 * Li * N;
+  ra.add0 = nullptr; ra.add1 = nullptr; ra.add_bstride = 0;
+  ra.beta_m = it->second.beta_m; ra.alpha_m = it->second.alpha_m; ra.klimbs = c->L + 1;
+  ra.tw = c->d_tw_fwd; ra.primes = c->d_primes; ra.omap = omap;
+  ra.nd = Li; ra.nout = nout; ra.logN = c->logN; ra.logR = c->logR;
+  const u32 R = 1u << c->logR, rows = R < 16 ? R : 16;
+  ra.nb = batch; ra.rb_count = R / rows;
+  LAUNCH_SP(c, "relin_rows_mac", relin_rows_mac_kernel, dim3(batch * (R / rows) * nout), dim3(16 * rows), ra);
+  // rescale by the special prime (:475-515): entries = 2*batch polys of Li+1 limbs, last limb lives under P[L]
+  NttPlan pl{ans + (size_t)Li * N, ans + (size_t)Li * N, c->d_iota + c->L, 1, 1, 1, 1, 2 * batch, (u64)nout * N, (u64)nout * N};
+  TRY(ntt_run(c, pl, true));
+  TRY(ensure_ws(c, 2, (size_t)2 * batch * Li * N * 8));
+  u64 *tail = (u64 *)c->ws[2];
+  NttPlan ptl{ans + (size_t)Li * N, tail, c->d_iota, 1, Li, 1, Li, 2 * batch, (u64)nout * N, (u64)Li * N};
+  TRY(ntt_run(c, ptl, false));
+  LAUNCH_SP(c, "rescale", rescale_kernel, pw_grid(c, Li, 2 * batch), dim3(PW_THREADS), ct, (const u64 *)ans, (const u64 *)tail,
+            (const u64 *)(c->d_qinv_m + (size_t)c->L * c->M), (const PrimeC *)c->d_primes, nout, N);
+  // rop[0] = ct[0] + ... (:503-514): add galois(bx) onto the bx halves
+  LAUNCH(c, "add_strided", add_strided_kernel, pw_grid(c, Li, batch), dim3(PW_THREADS), ct, (const u64 *)g, (const PrimeC *)c->d_primes, N,
+         (u64)2 * Li * N, (u64)2 * Li * N);
+  return FHE_HIP_OK;
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -548,6 +608,7 @@ void fhe_hip_ctx_destroy(fhe_hip_ctx *c) {
                   c->d_hat_qj_inv_m, c->d_hat_qj_pi_m, c->d_qinv_m, c->d_mk_beta, c->d_mk_alpha};
   for (void *p : ptrs) if (p) hipFree(p);
   for (auto &kv : c->rot_keys) { hipFree(kv.second.beta_m); hipFree(kv.second.alpha_m); }
+  for (auto &kv : c->mixed_keys) { hipFree(kv.second.beta_m); hipFree(kv.second.alpha_m); }
   for (auto &kv : c->galois_perm) hipFree(kv.second);
   for (void *p : c->ws) if (p) hipFree(p);
   for (void *p : c->stage) if (p) hipFree(p);
@@ -785,6 +846,83 @@ int fhe_hip_rotate(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, s
   TRY(st.out(ct, batch * 2 * Li * c->N * 8, &d, true));
   TRY(dev_rotate(c, galois, d, Li, (u32)batch));
   return st.finish();
+}
+
+int fhe_hip_load_mixed_rot_key(fhe_hip_ctx *c, uint64_t galois, const uint64_t *beta, const uint64_t *alpha, int mem_kind) {
+  TRY(check_ctx(c));
+  if (!beta || !alpha) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (c->K < 1) FAIL(c, FHE_HIP_ERR_RANGE, "mixed rotation keys need one special prime");
+  if (galois != 0 && (!(galois & 1) || galois >= 2 * c->N)) FAIL(c, FHE_HIP_ERR_ARG, "galois must be odd and < 2N");
+  MixedRotKeyDev &rk = c->mixed_keys[galois];
+  // [L][L+1][N]: limb id = i*(L+1) + j uses modulus j = id % (L+1) (limb L is the special prime P[L])
+  TRY(load_key(c, &rk.beta_m, beta, (size_t)c->L * (c->L + 1), c->d_iota, c->L + 1, mem_kind));
+  TRY(load_key(c, &rk.alpha_m, alpha, (size_t)c->L * (c->L + 1), c->d_iota, c->L + 1, mem_kind));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return FHE_HIP_OK;
+}
+
+int fhe_hip_rotate_mixed(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind) {
+  TRY(check_ctx(c));
+  if (!ct) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (galois == 0) return FHE_HIP_OK;  // evaluator.cpp:317-318
+  if (!(galois & 1) || galois >= 2 * c->N) FAIL(c, FHE_HIP_ERR_ARG, "galois must be odd and < 2N");
+  TRY(check_li(c, Li, 1));
+  if (c->K < 1) FAIL(c, FHE_HIP_ERR_RANGE, "mixed rotation needs one special prime");
+  if (batch == 0) return FHE_HIP_OK;
+  Staged st(c, mem_kind);
+  u64 *d = nullptr;
+  TRY(st.out(ct, batch * 2 * Li * c->N * 8, &d, true));
+  TRY(dev_rotate_mixed(c, galois, d, Li, (u32)batch));
+  return st.finish();
+}
+
+int fhe_hip_decrypt(fhe_hip_ctx *c, uint64_t *out, const uint64_t *ct, const uint64_t *sx, uint32_t Li, size_t batch, int mem_kind) {
+  TRY(check_ctx(c));
+  if (!out || !ct || !sx) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (Li < 1 || Li > c->L) FAIL(c, FHE_HIP_ERR_RANGE, "Impossible.");  // decryptor.cpp:17-18
+  if (batch == 0) return FHE_HIP_OK;
+  const u64 N = c->N;
+  Staged st(c, mem_kind);
+  const u64 *dct = nullptr, *dsx = nullptr; u64 *dout = nullptr;
+  TRY(st.in(ct, batch * 2 * Li * N * 8, &dct));
+  TRY(st.in(sx, (size_t)Li * N * 8, &dsx));
+  TRY(st.out(out, batch * Li * N * 8, &dout, false));
+  LAUNCH_SP(c, "decrypt_mac", decrypt_mac_kernel, pw_grid(c, Li, (u32)batch), dim3(PW_THREADS), dout, dct, dsx, (const PrimeC *)c->d_primes, Li, N);
+  TRY(ntt_simple(c, dout, c->d_iota, Li, (u32)batch, (u64)Li * N, true));  // rop->backward(), decryptor.cpp:36
+  return st.finish();
+}
+
+int fhe_hip_encrypt(fhe_hip_ctx *c, uint64_t *ct, const uint64_t *u, const uint64_t *e0m, const uint64_t *e1, const uint64_t *pk_b,
+                    const uint64_t *pk_a, uint32_t Li, size_t batch, int mem_kind) {
+  TRY(check_ctx(c));
+  if (!ct || !u || !e0m || !e1 || !pk_b || !pk_a) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (Li < 1 || Li > c->L) FAIL(c, FHE_HIP_ERR_RANGE, "bad limb count");
+  if (batch == 0) return FHE_HIP_OK;
+  const u64 N = c->N;
+  const size_t pb = (size_t)Li * N * 8;
+  // host buffers: 6 inputs + 1 output exceed the staging slots, so the polynomials are staged by hand
+  TRY(ensure_ws(c, 0, batch * pb));
+  TRY(ensure_ws(c, 3, batch * 2 * pb));
+  TRY(ensure_ws(c, 4, 2 * pb));
+  u64 *uh = (u64 *)c->ws[0], *dct = mem_kind == FHE_HIP_MEM_DEVICE ? (u64 *)ct : (u64 *)c->ws[3];
+  u64 *dpk = (u64 *)c->ws[4];
+  const hipMemcpyKind in_kind = mem_kind == FHE_HIP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  HIPCHK(c, hipMemcpyAsync(uh, u, batch * pb, in_kind, c->stream));
+  for (size_t b = 0; b < batch; ++b) {
+    HIPCHK(c, hipMemcpyAsync(dct + b * 2 * Li * N, e0m + b * Li * N, pb, in_kind, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dct + (b * 2 + 1) * Li * N, e1 + b * Li * N, pb, in_kind, c->stream));
+  }
+  HIPCHK(c, hipMemcpyAsync(dpk, pk_b, pb, in_kind, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dpk + (size_t)Li * N, pk_a, pb, in_kind, c->stream));
+  TRY(ntt_simple(c, uh, c->d_iota, Li, (u32)batch, (u64)Li * N, false));           // u.forward(), encryptor.cpp:16
+  TRY(ntt_simple(c, dct, c->d_iota, Li, 2 * (u32)batch, (u64)Li * N, false));     // bx/ax.forward_lazy(), :30,34
+  LAUNCH_SP(c, "encrypt_mac", encrypt_mac_kernel, pw_grid(c, Li, (u32)batch), dim3(PW_THREADS), dct, (const u64 *)uh, (const u64 *)dpk,
+            (const u64 *)(dpk + (size_t)Li * N), (const PrimeC *)c->d_primes, Li, N);
+  if (mem_kind != FHE_HIP_MEM_DEVICE) {
+    HIPCHK(c, hipMemcpyAsync(ct, dct, batch * 2 * pb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return FHE_HIP_OK;
 }
 
 int fhe_hip_profile_enable(fhe_hip_ctx *c, int on) { TRY(check_ctx(c)); c->prof = on != 0; return FHE_HIP_OK; }

@@ -261,12 +261,20 @@ __global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs
 // NTT is the identity on ct[2] limb i (NTT_i(INTT_i(x)) = x), so it is read directly.
 // t1 = [b][Li(i)][Li(j)][N]; ct3 = [b][3][Li][N]; out = [b][2][Li][N]; keys [L][L][N] Montgomery form.
 // ---------------------------------------------------------------------------------------------
+// The same kernel serves the MixedRotKey key switch (src/evaluator.cpp:424-473): there the output limbs are the Li
+// normal primes plus the special prime P[L] (omap), the digits are the limbs of galois(ax), the diagonal digit is ct[1]
+// itself (:436-437) and nothing is added.
 struct RelinArgs {
-  const u64 *t1; const u64 *ct3; u64 *out;
-  const u64 *beta_m, *alpha_m;
+  const u64 *t1;           // [b][nout][nd][N] column-pass output
+  const u64 *diag;         // digit j == output limb i: [b](diag_bstride)[limb][N], read directly
+  const u64 *add0, *add1;  // optional addends per half: [b](add_bstride)[limb][N]; null = none
+  u64 *out;                // [b][2][nout][N]
+  const u64 *beta_m, *alpha_m;  // [key j][klimbs][N] Montgomery form
   const u64 *tw; const PrimeC *primes;
-  u32 Li, L, logN, logR, i0;
-  u32 nb, rb_count;  // batch entries and row blocks per limb (grid decode)
+  const u32 *omap;         // output limb -> global modulus index (also the key limb index)
+  u64 diag_bstride, add_bstride;
+  u32 nd, nout, klimbs, logN, logR;
+  u32 nb, rb_count;        // batch entries and row blocks per limb (grid decode)
 };
 
 template <bool SP>
@@ -282,9 +290,9 @@ __global__ __launch_bounds__(256) void relin_rows_mac_kernel(RelinArgs a) {
   {
     const u32 id = blockIdx.x, nb = a.nb, RB = a.rb_count;
     if ((RB & 7) == 0) {
-      const u32 xcd = id & 7, m = id >> 3;
-      b = m % nb;
-      const u32 rest = m / nb;
+      const u32 xcd = id & 7, q = id >> 3;
+      b = q % nb;
+      const u32 rest = q / nb;
       rb = xcd + 8 * (rest % (RB >> 3));
       i = rest / (RB >> 3);
     } else {
@@ -292,30 +300,30 @@ __global__ __launch_bounds__(256) void relin_rows_mac_kernel(RelinArgs a) {
       rb = (id / nb) % RB;
       i = id / (nb * RB);
     }
-    i += a.i0;
   }
   const u32 row = rb * rows_per_wg + rloc;
-  const u32 Li = a.Li;
-  const PrimeC P = a.primes[i];
+  const u32 nd = a.nd;
+  const u32 m = a.omap[i];
+  const PrimeC P = a.primes[m];
   const u64 N = 1ull << a.logN;
-  const u64 *__restrict__ tw = a.tw + (u64)i * N;
+  const u64 *__restrict__ tw = a.tw + (u64)m * N;
   u64 *L = lds + rloc * ROW_LDS;
   const u32 baseA = (1u << a.logR) + row;
   const u64 row_off = (u64)row * 256;
   u64 acc0[16], acc1[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) { acc0[k] = 0; acc1[k] = 0; }
-  for (u32 j = 0; j < Li; ++j) {
+  for (u32 j = 0; j < nd; ++j) {
     u64 x[16];
     if (j == i) {
-      const u64 *s = a.ct3 + (((u64)b * 3 + 2) * Li + i) * N + row_off;
+      const u64 *s = a.diag + (u64)b * a.diag_bstride + (u64)i * N + row_off;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&s[32 * q + 2 * t]);
         x[2 * q] = v.x; x[2 * q + 1] = v.y;
       }
     } else {
-      const u64 *s = a.t1 + (((u64)b * Li + i) * Li + j) * N + row_off;
+      const u64 *s = a.t1 + (((u64)b * a.nout + i) * nd + j) * N + row_off;
 #pragma unroll
       for (int k = 0; k < 16; ++k) x[k] = s[t + 16 * k];
       fwd_phase<SP, 4>(x, tw, baseA, P);
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(256) void relin_rows_mac_kernel(RelinArgs a) {
       wave_lds_sync();
     }
     // key MAC in the coalesced layout: lane t owns elements {32q + 2t, 32q + 2t + 1}; x may be lazy (< 4p)
-    const u64 koff = ((u64)j * a.L + i) * N + row_off;
+    const u64 koff = ((u64)j * a.klimbs + m) * N + row_off;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(&a.beta_m[koff + 32 * q + 2 * t]);
@@ -351,15 +359,17 @@ __global__ __launch_bounds__(256) void relin_rows_mac_kernel(RelinArgs a) {
       acc1[2 * q + 1] = csub(acc1[2 * q + 1] + mont_mul<SP>(ka.y, x[2 * q + 1], P), P.twop);
     }
   }
-  const u64 half = (u64)Li * N;
-  const u64 *c = a.ct3 + ((u64)b * 3 * Li + i) * N + row_off;
-  u64 *o = a.out + ((u64)b * 2 * Li + i) * N + row_off;
+  const u64 half = (u64)a.nout * N;
+  u64 *o = a.out + ((u64)b * 2 * a.nout + i) * N + row_off;
+  const u64 *c0 = a.add0 ? a.add0 + (u64)b * a.add_bstride + (u64)i * N + row_off : nullptr;
+  const u64 *c1 = a.add1 ? a.add1 + (u64)b * a.add_bstride + (u64)i * N + row_off : nullptr;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const u32 e = 32 * q + 2 * t;
-    const ulonglong2 d0 = *reinterpret_cast<const ulonglong2 *>(&c[e]);
-    const ulonglong2 d1 = *reinterpret_cast<const ulonglong2 *>(&c[half + e]);
-    *reinterpret_cast<ulonglong2 *>(&o[e]) = make_ulonglong2(csub(csub(acc0[2 * q], P.p) + d0.x, P.p), csub(csub(acc0[2 * q + 1], P.p) + d0.y, P.p));
-    *reinterpret_cast<ulonglong2 *>(&o[half + e]) = make_ulonglong2(csub(csub(acc1[2 * q], P.p) + d1.x, P.p), csub(csub(acc1[2 * q + 1], P.p) + d1.y, P.p));
+    u64 r00 = csub(acc0[2 * q], P.p), r01 = csub(acc0[2 * q + 1], P.p), r10 = csub(acc1[2 * q], P.p), r11 = csub(acc1[2 * q + 1], P.p);
+    if (c0) { const ulonglong2 d0 = *reinterpret_cast<const ulonglong2 *>(&c0[e]); r00 = csub(r00 + d0.x, P.p); r01 = csub(r01 + d0.y, P.p); }
+    if (c1) { const ulonglong2 d1 = *reinterpret_cast<const ulonglong2 *>(&c1[e]); r10 = csub(r10 + d1.x, P.p); r11 = csub(r11 + d1.y, P.p); }
+    *reinterpret_cast<ulonglong2 *>(&o[e]) = make_ulonglong2(r00, r01);
+    *reinterpret_cast<ulonglong2 *>(&o[half + e]) = make_ulonglong2(r10, r11);
   }
 }

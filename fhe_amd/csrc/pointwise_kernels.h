@@ -189,6 +189,16 @@ __global__ __launch_bounds__(PW_THREADS) void galois_coeff_kernel(u64 *dst, cons
   dst[o + (raw & (N - 1))] = ((raw >> logN) & 1) ? (t > 0 ? p - t : 0) : t;
 }
 
+// rop[e][l] += op[e][l] with separate batch strides (elements): "rop[0] = ct[0] + ..." of evaluator.cpp:503-514
+__global__ __launch_bounds__(PW_THREADS) void add_strided_kernel(u64 *rop, const u64 *op, const PrimeC *primes, u64 N, u64 rop_bstride,
+                                                                 u64 op_bstride) {
+  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
+  const u64 p = primes[blockIdx.y].p;
+  u64 *r = rop + (u64)blockIdx.z * rop_bstride + (u64)blockIdx.y * N + d;
+  const ulonglong2 a = ld2(r), b = ld2(op + (u64)blockIdx.z * op_bstride + (u64)blockIdx.y * N + d);
+  st2(r, addmod_c(a.x, b.x, p), addmod_c(a.y, b.y, p));
+}
+
 // poly operator+= (src/evaluator.cpp:284-285): rop, op = [e][nl][N], limb k uses modulus k
 __global__ __launch_bounds__(PW_THREADS) void add_kernel(u64 *rop, const u64 *op, const PrimeC *primes, u64 N) {
   const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
@@ -217,4 +227,32 @@ __global__ __launch_bounds__(PW_THREADS) void to_mont_kernel(u64 *x, const Prime
   const u64 o = (u64)blockIdx.y * N + d;
   const ulonglong2 v = ld2(x + o);
   st2(x + o, to_mont<SP>(v.x, P), to_mont<SP>(v.y, P));
+}
+
+// Decryptor::decrypt lazy loop (src/decryptor.cpp:24-34): out[e][l] = (bx + sx[l]*ax) mod q_l; ct = [e][2][Li][N]
+template <bool SP>
+__global__ __launch_bounds__(PW_THREADS) void decrypt_mac_kernel(u64 *out, const u64 *ct, const u64 *sx, const PrimeC *primes, u32 Li,
+                                                                 u64 N) {
+  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
+  const u32 l = blockIdx.y, e = blockIdx.z;
+  const PrimeC P = primes[l];
+  const u64 in = ((u64)e * 2 * Li + l) * N + d;
+  const ulonglong2 b = ld2(ct + in), a = ld2(ct + in + (u64)Li * N), s = ld2(sx + (u64)l * N + d);
+  st2(out + ((u64)e * Li + l) * N + d, addmod_c(mulmod_full<SP>(s.x, a.x, P), csub(b.x, P.p), P.p),
+      addmod_c(mulmod_full<SP>(s.y, a.y, P), csub(b.y, P.p), P.p));
+}
+
+// Encryptor::encrypt add_product_of steps (src/encryptor.cpp:31,35): ct[e][0][l] = e0m^ + u^*pk_b, ct[e][1][l] = e1^ + u^*pk_a
+// uh / ct halves hold the forward NTTs already; ct = [e][2][Li][N] in place, uh = [e][Li][N]
+template <bool SP>
+__global__ __launch_bounds__(PW_THREADS) void encrypt_mac_kernel(u64 *ct, const u64 *uh, const u64 *pk_b, const u64 *pk_a,
+                                                                 const PrimeC *primes, u32 Li, u64 N) {
+  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
+  const u32 l = blockIdx.y, e = blockIdx.z;
+  const PrimeC P = primes[l];
+  const u64 o = ((u64)e * 2 * Li + l) * N + d, half = (u64)Li * N;
+  const ulonglong2 u = ld2(uh + ((u64)e * Li + l) * N + d), b = ld2(ct + o), a = ld2(ct + o + half);
+  const ulonglong2 kb = ld2(pk_b + (u64)l * N + d), ka = ld2(pk_a + (u64)l * N + d);
+  st2(ct + o, addmod_c(mulmod_full<SP>(kb.x, u.x, P), b.x, P.p), addmod_c(mulmod_full<SP>(kb.y, u.y, P), b.y, P.p));
+  st2(ct + o + half, addmod_c(mulmod_full<SP>(ka.x, u.x, P), a.x, P.p), addmod_c(mulmod_full<SP>(ka.y, u.y, P), a.y, P.p));
 }

@@ -76,6 +76,10 @@ def load_library():
         "fhe_hip_relinearize": (i, [vp, vp, vp, u32, sz, i]),
         "fhe_hip_mul_relin_rescale": (i, [vp, vp, vp, vp, u32, sz, i]),
         "fhe_hip_rotate": (i, [vp, u64, vp, u32, sz, i]),
+        "fhe_hip_load_mixed_rot_key": (i, [vp, u64, vp, vp, i]),
+        "fhe_hip_rotate_mixed": (i, [vp, u64, vp, u32, sz, i]),
+        "fhe_hip_decrypt": (i, [vp, vp, vp, vp, u32, sz, i]),
+        "fhe_hip_encrypt": (i, [vp, vp, vp, vp, vp, vp, vp, u32, sz, i]),
         "fhe_hip_profile_enable": (i, [vp, i]),
         "fhe_hip_profile_reset": (i, [vp]),
         "fhe_hip_profile_get": (i, [vp, C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double), i]),
@@ -92,7 +96,7 @@ EXPORTED_SYMBOLS = [
     "fhe_hip_ntt_forward", "fhe_hip_ntt_backward", "fhe_hip_apply_galois", "fhe_hip_apply_galois_non_ntt",
     "fhe_hip_mod_up", "fhe_hip_mod_down", "fhe_hip_rescale", "fhe_hip_load_mult_key", "fhe_hip_load_rot_key",
     "fhe_hip_add", "fhe_hip_multiply_plain", "fhe_hip_cross_mult", "fhe_hip_relin_only", "fhe_hip_relinearize",
-    "fhe_hip_mul_relin_rescale", "fhe_hip_rotate", "fhe_hip_profile_enable", "fhe_hip_profile_reset",
+    "fhe_hip_mul_relin_rescale", "fhe_hip_rotate", "fhe_hip_load_mixed_rot_key", "fhe_hip_rotate_mixed", "fhe_hip_decrypt", "fhe_hip_encrypt", "fhe_hip_profile_enable", "fhe_hip_profile_reset",
     "fhe_hip_profile_get",
 ]
 
@@ -240,6 +244,27 @@ class HipContext:
     def rotate(self, galois, ct, Li, batch=1):
         (c,), kind = _same_kind(ct)
         self._chk(self.lib.fhe_hip_rotate(self.h, galois, c, Li, batch, kind))
+        return ct
+
+    # ---- MixedRotKey variant -----------------------------------------
+    def load_mixed_rot_key(self, galois, beta, alpha):
+        (b, a), kind = _same_kind(beta, alpha)
+        self._chk(self.lib.fhe_hip_load_mixed_rot_key(self.h, galois, b, a, kind))
+
+    def rotate_mixed(self, galois, ct, Li, batch=1):
+        (c,), kind = _same_kind(ct)
+        self._chk(self.lib.fhe_hip_rotate_mixed(self.h, galois, c, Li, batch, kind))
+        return ct
+
+    # ---- the steps either side of the path ----------------------------
+    def decrypt(self, out, ct, sx, Li, batch=1):
+        (o, c, s), kind = _same_kind(out, ct, sx)
+        self._chk(self.lib.fhe_hip_decrypt(self.h, o, c, s, Li, batch, kind))
+        return out
+
+    def encrypt(self, ct, u, e0m, e1, pk_b, pk_a, Li, batch=1):
+        ptrs, kind = _same_kind(ct, u, e0m, e1, pk_b, pk_a)
+        self._chk(self.lib.fhe_hip_encrypt(self.h, *ptrs, Li, batch, kind))
         return ct
 
     # ---- measurement ------------------------------------------------------------------------

@@ -99,6 +99,23 @@ int fhe_hip_mul_relin_rescale(fhe_hip_ctx *ctx, uint64_t *out, const uint64_t *c
  * in place with the RotKey loaded for `galois`; galois == 0 is a no-op (:303-304). */
 int fhe_hip_rotate(fhe_hip_ctx *ctx, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind);
 
+/* MixedRotKey (include/fHE/rot_key.hpp:41-82, src/rot_key.cpp:81-120): beta/alpha = [L][L+1][N] (key i, limb j; limb L
+ * lives under the special prime P[L]), NTT basis.   */
+int fhe_hip_load_mixed_rot_key(fhe_hip_ctx *ctx, uint64_t galois, const uint64_t *beta, const uint64_t *alpha, int mem_kind);
+/* Evaluator::rotate_slots(Cipher*, MixedRotKey const&) (src/evaluator.cpp:148-156, 313-325, 403-516): digit-decomposed
+ * key switch over Li+1 limbs with the fused rescale by P[L]; ct = [batch][2][Li][N] in place. */
+int fhe_hip_rotate_mixed(fhe_hip_ctx *ctx, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind);
+
+/* Decryptor::decrypt(poly_t*, Cipher const&, SK const&) inner loops (src/decryptor.cpp:24-36): ct = [batch][2][Li][N]
+ * canonical NTT basis, sx = [>=Li][N] secret key (NTT basis) -> out = [batch][Li][N] = INTT(bx + sx*ax), power basis.
+ * (the step right after the path.) */
+int fhe_hip_decrypt(fhe_hip_ctx *ctx, uint64_t *out, const uint64_t *ct, const uint64_t *sx, uint32_t Li, size_t batch, int mem_kind);
+/* Encryptor::encrypt inner loops (src/encryptor.cpp:15-35) with the sampled polynomials supplied by the caller (the
+ * samplers stay on the host): u, e0m (= e0 + msg), e1 = [batch][Li][N] power basis; pk_b, pk_a = [>=Li][N] NTT basis
+ * -> ct = [batch][2][Li][N] with bx = NTT(e0m) + NTT(u)*pk_b, ax = NTT(e1) + NTT(u)*pk_a.  (§8(f) rank 3.) */
+int fhe_hip_encrypt(fhe_hip_ctx *ctx, uint64_t *ct, const uint64_t *u, const uint64_t *e0m, const uint64_t *e1,
+                    const uint64_t *pk_b, const uint64_t *pk_a, uint32_t Li, size_t batch, int mem_kind);
+
 /* Measurement support (no reference counterpart): when enabled every kernel launch is bracketed by
  * HIP events on the context's stream; stats are summed per kernel name. */
 int fhe_hip_profile_enable(fhe_hip_ctx *ctx, int on);

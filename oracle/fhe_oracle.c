@@ -468,6 +468,58 @@ int orc_rotate(const orc_ctx *c, u64 *bx, u64 *ax, uint32_t Li, u64 galois, cons
   return 0;
 }
 
+int orc_rotate_mixed(const orc_ctx *c, u64 *bx, u64 *ax, uint32_t Li, u64 galois, const u64 *mk_beta, const u64 *mk_alpha) {
+  /* rotate_slots_inplace(MixedRotKey) evaluator.cpp:313-325 + apply_rotation_key(MixedRotKey) :403-516 */
+  if (!bx || !ax) return -1;
+  if (galois == 0) return 0;
+  if (Li < 1 || Li > c->L || c->K < 1) return -1;
+  const size_t N = c->N; const uint32_t L = c->L, k = L; /* k = index_sp_prime(0) */
+  const size_t kl = (size_t)(L + 1) * N;               /* one key polynomial */
+  orc_apply_galois(c, bx, Li, galois);
+  orc_apply_galois(c, ax, Li, galois);
+  u128 *bacc = (u128 *)calloc((size_t)(Li + 1) * N, sizeof(u128)), *aacc = (u128 *)calloc((size_t)(Li + 1) * N, sizeof(u128));
+  u64 *pw = (u64 *)malloc(N * 8), *v = (u64 *)malloc(N * 8);
+  for (uint32_t i = 0; i < Li; ++i) {
+    memcpy(pw, ax + (size_t)i * N, N * 8);
+    orc_ntt_backward(c, pw, i);                                            /* :425-427 */
+    for (uint32_t j = 0; j < Li + 1; ++j) {
+      const uint32_t jidx = j < Li ? j : k;
+      const u64 *src;
+      if (j == i) src = ax + (size_t)j * N;                                /* :436-437 */
+      else { memcpy(v, pw, N * 8); orc_ntt_forward(c, v, jidx); src = v; } /* :439-442 */
+      const u64 *bk = mk_beta + (size_t)i * kl + (size_t)jidx * N, *ak = mk_alpha + (size_t)i * kl + (size_t)jidx * N;
+      u128 *b_ = bacc + (size_t)j * N, *a_ = aacc + (size_t)j * N;
+      for (size_t d = 0; d < N; ++d) { b_[d] += (u128)bk[d] * src[d]; a_[d] += (u128)ak[d] * src[d]; } /* :445-451 */
+      if ((i & 15) == 15) for (size_t d = 0; d < N; ++d) { b_[d] = reduce128(c, b_[d], jidx); a_[d] = reduce128(c, a_[d], jidx); }
+    }
+  }
+  u64 *ans_b = (u64 *)malloc((size_t)(Li + 1) * N * 8), *ans_a = (u64 *)malloc((size_t)(Li + 1) * N * 8);
+  for (uint32_t j = 0; j < Li + 1; ++j) {                                  /* :456-473 */
+    const uint32_t jidx = j < Li ? j : k;
+    for (size_t d = 0; d < N; ++d) {
+      ans_b[(size_t)j * N + d] = reduce128(c, bacc[(size_t)j * N + d], jidx);
+      ans_a[(size_t)j * N + d] = reduce128(c, aacc[(size_t)j * N + d], jidx);
+    }
+  }
+  orc_ntt_backward(c, ans_a + (size_t)Li * N, k);                          /* :479-480 */
+  orc_ntt_backward(c, ans_b + (size_t)Li * N, k);
+  const u64 qk = c->P[k];
+  for (uint32_t j = 0; j < Li; ++j) {                                      /* :485-515 */
+    const u64 qj = c->P[j], qinv = orc_invmod(qk % qj, qj), qs = orc_shoupify(qinv, qj);
+    memcpy(v, ans_a + (size_t)Li * N, N * 8);
+    orc_ntt_forward(c, v, j);
+    for (size_t d = 0; d < N; ++d) ax[(size_t)j * N + d] = orc_mulmod_shoup(ans_a[(size_t)j * N + d] + qj - v[d], qinv, qs, qj);
+    memcpy(v, ans_b + (size_t)Li * N, N * 8);
+    orc_ntt_forward(c, v, j);
+    for (size_t d = 0; d < N; ++d) {
+      u64 t = orc_mulmod_shoup(ans_b[(size_t)j * N + d] + qj - v[d], qinv, qs, qj);
+      bx[(size_t)j * N + d] = orc_addmod(bx[(size_t)j * N + d], t, qj);
+    }
+  }
+  free(bacc); free(aacc); free(pw); free(v); free(ans_b); free(ans_a);
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* plumbing: samplers and key generation (host only; streams are this repo's, not yell's)       */
 /* ------------------------------------------------------------------------------------------ */
@@ -585,6 +637,35 @@ void orc_keygen_rot(const orc_ctx *c, u64 *beta, u64 *alpha, const u64 *sx, cons
   free(v); free(rot);
 }
 
+void orc_keygen_mixed_rot(const orc_ctx *c, u64 *beta, u64 *alpha, const u64 *sx, const u64 *ext_sx, u64 galois, u64 seed) {
+  /* rot_key.cpp:81-120: beta_j = -(e + alpha_j * s) + [qK * sigma_g(s)] on limb j, over L normal limbs + P[L] */
+  const size_t N = c->N; const uint32_t L = c->L; u64 st = seed;
+  const size_t kl = (size_t)(L + 1) * N;
+  int *v = (int *)malloc(N * sizeof(int));
+  u64 *ext = (u64 *)malloc(kl * 8), *rot = (u64 *)malloc(kl * 8);
+  memcpy(ext, sx, (size_t)L * N * 8); memcpy(ext + (size_t)L * N, ext_sx, N * 8);   /* :90-94 */
+  memcpy(rot, ext, kl * 8);
+  orc_apply_galois(c, rot, L + 1, galois);
+  const u64 qK = c->P[L];
+  for (uint32_t j = 0; j < L; ++j) {
+    u64 *bj = beta + (size_t)j * kl, *aj = alpha + (size_t)j * kl;
+    orc_uniform_poly(c, aj, 0, L + 1, seed ^ (0x51EDull * (j + 1)));
+    sample_gauss(v, N, &st);
+    set_small(c, bj, v, 0, L + 1);
+    for (uint32_t cm = 0; cm < L + 1; ++cm) {
+      const u64 p = c->P[cm]; u64 *b = bj + (size_t)cm * N; const u64 *a = aj + (size_t)cm * N, *s = ext + (size_t)cm * N;
+      orc_ntt_forward(c, b, cm);
+      for (size_t d = 0; d < N; ++d) {
+        u64 t = orc_addmod(b[d], orc_mulmod(a[d], s[d], p), p);
+        t = t ? p - t : 0;
+        if (cm == j) t = orc_addmod(t, orc_mulmod(rot[(size_t)j * N + d], qK % p, p), p);   /* :111-116 */
+        b[d] = t;
+      }
+    }
+  }
+  free(v); free(ext); free(rot);
+}
+
 void orc_encrypt(const orc_ctx *c, u64 *bx, u64 *ax, const u64 *msg, uint32_t Li, const u64 *pk_b, const u64 *pk_a, u64 seed) {
   /* encryptor.cpp:9-37 */
   const size_t N = c->N; u64 st = seed;
@@ -604,6 +685,22 @@ void orc_encrypt(const orc_ctx *c, u64 *bx, u64 *ax, const u64 *msg, uint32_t Li
     }
   }
   free(v); free(u);
+}
+
+void orc_encrypt_core(const orc_ctx *c, u64 *bx, u64 *ax, const u64 *u, const u64 *e0m, const u64 *e1, uint32_t Li,
+                      const u64 *pk_b, const u64 *pk_a) { /* encryptor.cpp:15-35 */
+  const size_t N = c->N;
+  u64 *uh = (u64 *)malloc(N * 8);
+  for (uint32_t cm = 0; cm < Li; ++cm) {
+    const u64 p = c->P[cm]; const size_t o = (size_t)cm * N;
+    memcpy(uh, u + o, N * 8); memcpy(bx + o, e0m + o, N * 8); memcpy(ax + o, e1 + o, N * 8);
+    orc_ntt_forward(c, uh, cm); orc_ntt_forward(c, bx + o, cm); orc_ntt_forward(c, ax + o, cm);
+    for (size_t d = 0; d < N; ++d) {
+      bx[o + d] = orc_addmod(bx[o + d], orc_mulmod(uh[d], pk_b[o + d], p), p);
+      ax[o + d] = orc_addmod(ax[o + d], orc_mulmod(uh[d], pk_a[o + d], p), p);
+    }
+  }
+  free(uh);
 }
 
 void orc_decrypt(const orc_ctx *c, u64 *rop, const u64 *bx, const u64 *ax, uint32_t Li, const u64 *sx) { /* decryptor.cpp:11-38 */

@@ -88,6 +88,13 @@ void orc_multiply_plain(const orc_ctx *c, uint64_t *bx, uint64_t *ax, const uint
 int orc_rotate(const orc_ctx *c, uint64_t *bx, uint64_t *ax, uint32_t Li, uint64_t galois,
                const uint64_t *rk_beta, const uint64_t *rk_alpha);
 
+/* MixedRotKey variant: rotate_slots(MixedRotKey) evaluator.cpp:313-325 + apply_rotation_key
+ * :403-516; keys beta/alpha = [L][L+1][N] (key i, limb j; limb L is the special prime P[L]); needs K >= 1 */
+int orc_rotate_mixed(const orc_ctx *c, uint64_t *bx, uint64_t *ax, uint32_t Li, uint64_t galois,
+                     const uint64_t *mk_beta, const uint64_t *mk_alpha);
+void orc_keygen_mixed_rot(const orc_ctx *c, uint64_t *beta, uint64_t *alpha, const uint64_t *sx, const uint64_t *ext_sx,
+                          uint64_t galois, uint64_t seed);                                          /* rot_key.cpp:81-120 */
+
 /* ---- plumbing either side of the path (host only; seeds are this repo's) --------------------- */
 uint64_t orc_splitmix64(uint64_t *state);
 void orc_uniform_poly(const orc_ctx *c, uint64_t *poly, uint32_t first_idx, uint32_t nlimbs, uint64_t seed);
@@ -100,6 +107,10 @@ void orc_keygen_rot(const orc_ctx *c, uint64_t *beta, uint64_t *alpha, const uin
 /* encryptor.cpp:9-37; msg is an Li-limb power-basis plaintext */
 void orc_encrypt(const orc_ctx *c, uint64_t *bx, uint64_t *ax, const uint64_t *msg, uint32_t Li,
                  const uint64_t *pk_b, const uint64_t *pk_a, uint64_t seed);
+/* the arithmetic of encryptor.cpp:15-35 with the sampled polynomials given (power basis, Li limbs):
+ * bx = NTT(e0m) + NTT(u)*pk_b, ax = NTT(e1) + NTT(u)*pk_a, where e0m = e0 + msg */
+void orc_encrypt_core(const orc_ctx *c, uint64_t *bx, uint64_t *ax, const uint64_t *u, const uint64_t *e0m,
+                      const uint64_t *e1, uint32_t Li, const uint64_t *pk_b, const uint64_t *pk_a);
 /* decryptor.cpp:11-38: rop = INTT(bx + sx*ax), Li limbs, power basis */
 void orc_decrypt(const orc_ctx *c, uint64_t *rop, const uint64_t *bx, const uint64_t *ax, uint32_t Li, const uint64_t *sx);
 

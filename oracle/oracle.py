@@ -59,6 +59,9 @@ def _load():
         "orc_keygen_rot": (None, [vp, u64p, u64p, u64p, u64p, u64, u64]),
         "orc_encrypt": (None, [vp, u64p, u64p, u64p, u32, u64p, u64p, u64]),
         "orc_decrypt": (None, [vp, u64p, u64p, u64p, u32, u64p]),
+        "orc_rotate_mixed": (i, [vp, u64p, u64p, u32, u64, u64p, u64p]),
+        "orc_keygen_mixed_rot": (None, [vp, u64p, u64p, u64p, u64p, u64, u64]),
+        "orc_encrypt_core": (None, [vp, u64p, u64p, u64p, u64p, u64p, u32, u64p, u64p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -205,6 +208,19 @@ class Oracle:
             raise ValueError("rotate rc=%d" % rc)
         return bx, ax
 
+    def rotate_mixed(self, bx, ax, galois, mk_beta, mk_alpha):
+        bx, ax = bx.copy(), ax.copy()
+        rc = lib.orc_rotate_mixed(self.h, _p(bx), _p(ax), bx.shape[0], galois, _p(mk_beta), _p(mk_alpha))
+        if rc:
+            raise ValueError("rotate_mixed rc=%d" % rc)
+        return bx, ax
+
+    def keygen_mixed_rot(self, sx, ext_sx, galois, seed):
+        beta = np.zeros((self.L, self.L + 1, self.N), np.uint64)
+        alpha = np.zeros((self.L, self.L + 1, self.N), np.uint64)
+        lib.orc_keygen_mixed_rot(self.h, _p(beta), _p(alpha), _p(sx), _p(ext_sx), galois, seed)
+        return beta, alpha
+
     # --- plumbing --------------------------------------------------------------------------
     def uniform_poly(self, nlimbs, seed, first_idx=0):
         poly = np.zeros((nlimbs, self.N), np.uint64)
@@ -241,6 +257,13 @@ class Oracle:
         bx = np.zeros((Li, self.N), np.uint64)
         ax = np.zeros((Li, self.N), np.uint64)
         lib.orc_encrypt(self.h, _p(bx), _p(ax), _p(msg), Li, _p(pk_b), _p(pk_a), seed)
+        return bx, ax
+
+    def encrypt_core(self, u, e0m, e1, pk_b, pk_a):
+        Li = u.shape[0]
+        bx = np.zeros((Li, self.N), np.uint64)
+        ax = np.zeros((Li, self.N), np.uint64)
+        lib.orc_encrypt_core(self.h, _p(bx), _p(ax), _p(u), _p(e0m), _p(e1), Li, _p(pk_b), _p(pk_a))
         return bx, ax
 
     def decrypt(self, bx, ax, sx):

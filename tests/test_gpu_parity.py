@@ -278,3 +278,59 @@ def test_add_and_multiply_plain():
     g.multiply_plain(d, dev(pt), 4, batch=2)
     want = np.stack([np.stack(o.multiply_plain(ct[i, 0], ct[i, 1], pt)) for i in range(2)])
     assert np.array_equal(host(d), want)
+
+
+@pytest.mark.parametrize("Li", [4, 2])
+def test_encrypt_decrypt_inner_loops_on_device(Li):
+    """encryptor.cpp:15-35 / decryptor.cpp:24-36 on the device, sampled polynomials from the host."""
+    logN, L, K = 11, 4, 1
+    o, g = ctx_pair(logN, L, K)
+    sx, ext = o.keygen_sk(seed=140)
+    pkb, pka = o.keygen_pk(sx, seed=141)
+    B = 2
+    rng = np.random.default_rng(142)
+
+    def small(lo, hi):
+        v = rng.integers(lo, hi, o.N)
+        return np.stack([np.array([int(x) % int(o.primes[i]) for x in v], dtype=np.uint64) for i in range(Li)])
+
+    u = np.stack([small(-1, 2) for _ in range(B)])
+    e0m = np.stack([small(-(1 << 40), 1 << 40) for _ in range(B)])
+    e1 = np.stack([small(-8, 9) for _ in range(B)])
+    want = np.stack([np.stack(o.encrypt_core(u[b], e0m[b], e1[b], pkb, pka)) for b in range(B)])
+    ct = torch.zeros((B, 2, Li, o.N), dtype=torch.int64, device="cuda")
+    g.encrypt(ct, dev(u), dev(e0m), dev(e1), dev(pkb), dev(pka), Li, batch=B)
+    assert np.array_equal(host(ct), want)
+    # host-memory flavour of the same call
+    cth = np.zeros((B, 2, Li, o.N), np.uint64)
+    g.encrypt(cth, u, e0m, e1, pkb, pka, Li, batch=B)
+    assert np.array_equal(cth, want)
+    out = torch.zeros((B, Li, o.N), dtype=torch.int64, device="cuda")
+    g.decrypt(out, ct, dev(sx), Li, batch=B)
+    want_dec = np.stack([o.decrypt(want[b, 0], want[b, 1], sx) for b in range(B)])
+    assert np.array_equal(host(out), want_dec)
+    # decrypt(encrypt(m)) = m + small noise on limb 0
+    p0 = int(o.primes[0])
+    diff = (want_dec[0, 0].astype(object) - e0m[0, 0].astype(object)) % p0
+    assert int(np.minimum(diff, p0 - diff).max()) < 1 << 12
+
+
+@pytest.mark.parametrize("logN,L,K,Li,sp", [(10, 4, 1, 4, True), (10, 4, 2, 2, True), (11, 3, 1, 3, False), (12, 18, 1, 18, True), (10, 3, 1, 1, True)])
+def test_rotate_mixed_rot_key(logN, L, K, Li, sp):
+    """MixedRotKey key switch (evaluator.cpp:403-516) bit-exact vs the oracle."""
+    o, g = ctx_pair(logN, L, K, sp)
+    sx, ext = o.keygen_sk(seed=150)
+    gal = o.rotation_galois(2)
+    mkb, mka = o.keygen_mixed_rot(sx, ext, gal, seed=151)
+    g.load_mixed_rot_key(gal, dev(mkb), dev(mka))
+    B = 3
+    ct = np.stack([np.stack([rand_poly(o, range(Li), 160 + 2 * b), rand_poly(o, range(Li), 161 + 2 * b)]) for b in range(B)])
+    want = np.stack([np.stack(o.rotate_mixed(ct[b, 0], ct[b, 1], gal, mkb, mka)) for b in range(B)])
+    d = dev(ct)
+    g.rotate_mixed(gal, d, Li, batch=B)
+    assert np.array_equal(host(d), want)
+    d = dev(ct)
+    g.rotate_mixed(0, d, Li, batch=B)
+    assert np.array_equal(host(d), ct)
+    with pytest.raises(fhe_amd.FheHipError):
+        g.rotate_mixed(5, d, Li, batch=B)

@@ -323,3 +323,29 @@ def test_lazy_sum_is_exact_beyond_16_terms():
         Q *= m
     y = sum(((q[j] - 1) * pow(Q // q[j], -1, q[j]) % q[j]) * (Q // q[j]) for j in range(L))
     assert int(up[L, 0]) == y % int(o.primes[L])
+
+
+def test_mixed_rot_key_rotation_decrypts_to_rotated_plaintext():
+    """MixedRotKey key switch (evaluator.cpp:403-516) in the oracle, pinned by decryption."""
+    logN, L, K = 6, 3, 1
+    o = orc.Oracle(logN, L, K)
+    q = [int(v) for v in o.primes[:L]]
+    sx, ext = o.keygen_sk(seed=41, hwt=8)
+    pkb, pka = o.keygen_pk(sx, seed=42)
+    g = o.rotation_galois(2)
+    mkb, mka = o.keygen_mixed_rot(sx, ext, g, seed=43)
+    rng = np.random.default_rng(9)
+    scale = 1 << 50
+    m = [int(v) * scale for v in rng.integers(-8, 9, o.N)]
+    for Li in (3, 2):
+        cb, ca = o.encrypt(_encode_small(o, m, Li), pkb[:Li].copy(), pka[:Li].copy(), seed=44)
+        rb, ra = o.rotate_mixed(cb, ca, g, mkb, mka)
+        dec = _centered_crt(o.decrypt(rb, ra, sx), q[:Li])
+        want = [0] * o.N
+        for d in range(o.N):
+            e = d * g % (2 * o.N)
+            if e < o.N:
+                want[e] = m[d]
+            else:
+                want[e - o.N] = -m[d]
+        assert max(abs(x - y) for x, y in zip(dec, want)) < 1 << 30
