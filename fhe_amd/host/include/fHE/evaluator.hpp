@@ -13,6 +13,7 @@ struct Evaluator {
   std::shared_ptr<Encoder> encoder;
   mutable const MultKey *loaded_mkey_ = nullptr;
   mutable std::unordered_map<size_t, const RotKey *> loaded_rkeys_;
+  mutable std::unordered_map<size_t, const MixedRotKey *> loaded_mixed_;
   using T = yell::params::value_type;
 
   static fhe_hip_ctx *ctx() { return yell::runtime::get().ctx; }
@@ -133,8 +134,29 @@ struct Evaluator {
     return true;
   }
 
-  //! Rotation with arbitrary offset: binary decomposition over power-of-two keys (evaluator.cpp:184-208)
-  bool rotate_slots(Cipher *rop, int offset, RotKeySet<RotKey> const &rkeys) const {
+  //! MixedRotKey variant (evaluator.cpp:148-156, 313-325, 403-516)
+  bool rotate_slots(Cipher *rop, MixedRotKey const &rkey) const {
+    if (!rop) return false;
+    if (!rop->canonical()) { std::cerr << "Can only rotate canonical ciphertext, call relinearize first." << std::endl; return false; }
+    if (rkey.galois == 0) return true;
+    const size_t Li = rop->moduli_count(), N = context::degree, limbs = Li * N, L = context::nr_ctxt_moduli;
+    auto it = loaded_mixed_.find(rkey.galois);
+    if (it == loaded_mixed_.end() || it->second != &rkey) {
+      std::vector<T> beta(L * (L + 1) * N), alpha(L * (L + 1) * N);
+      for (size_t j = 0; j < L; ++j) { pack(beta, j * (L + 1) * N, *rkey.get_beta_at(j), L + 1); pack(alpha, j * (L + 1) * N, *rkey.get_alpha_at(j), L + 1); }
+      if (fhe_hip_load_mixed_rot_key(ctx(), rkey.galois, beta.data(), alpha.data(), FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
+      loaded_mixed_[rkey.galois] = &rkey;
+    }
+    std::vector<T> ct(2 * limbs);
+    pack(ct, 0, rop->bx, Li); pack(ct, limbs, rop->ax, Li);
+    if (fhe_hip_rotate_mixed(ctx(), rkey.galois, ct.data(), (uint32_t)Li, 1, FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
+    std::memcpy(rop->bx.ptr_at(0), ct.data(), limbs * sizeof(T));
+    std::memcpy(rop->ax.ptr_at(0), ct.data() + limbs, limbs * sizeof(T));
+    return true;
+  }
+
+  //! Rotation with arbitrary offset: binary decomposition over power-of-two keys (evaluator.cpp:158-208)
+  template <class RotKeyT> bool rotate_slots(Cipher *rop, int offset, RotKeySet<RotKeyT> const &rkeys) const {
     if (!rop) return false;
     if (!rop->canonical()) { std::cerr << "Can only rotate canonical ciphertext, call relinearize first." << std::endl; return false; }
     const size_t nr_slots = context::degree >> 1u;

@@ -1,5 +1,4 @@
 // fHE/rot_key.hpp — RotKey / RotKeySet of reference include/fHE/rot_key.hpp:9-39,84-118 + src/rot_key.cpp:6-79.
-// (MixedRotKey is a SURVEY §8(f) "next" row.)
 #pragma once
 #include "fHE/context.hpp"
 #include "fHE/keys.hpp"
@@ -68,6 +67,52 @@ struct RotKey {
   }
   RotKey(RotKey const &) = delete; RotKey(RotKey &&) = delete; RotKey &operator=(RotKey const &) = delete;
   ~RotKey() {}
+};
+
+// MixedRotKey (reference include/fHE/rot_key.hpp:41-82, src/rot_key.cpp:81-120): digit-decomposed rotation key with
+// ONE special prime; L polynomials of L + 1 moduli each.
+struct MixedRotKey {
+ private:
+  using poly_t = context::poly_t;
+  std::vector<poly_t> alpha;  // L polynomials, each L + 1 moduli
+  std::vector<poly_t> beta;
+
+ public:
+  enum class Direction { LEFT, RIGHT };
+  const size_t galois;
+
+  explicit MixedRotKey(SK const &sk, uint16_t offset, Direction dir)
+      : galois(rotation_offset_galois(dir == Direction::RIGHT ? offset : -(int)offset)) {
+    using T = yell::params::value_type;
+    const size_t L = context::nr_ctxt_moduli, degree = context::degree, bytes = degree * sizeof(T);
+    for (size_t j = 0; j < L; ++j) { beta.emplace_back(L + 1); alpha.emplace_back(L + 1, yell::uniform{}); }
+    context::poly_t ext_sx(L + 1);
+    for (size_t j = 0; j < L + 1; ++j) std::memcpy(ext_sx.ptr_at(j), j < L ? sk.sx.cptr_at(j) : sk.ext_sx.cptr_at(0), bytes);
+    auto rotated_sx(ext_sx);
+    apply_galois(&rotated_sx, galois);
+    // beta_j = -sx * alpha_j + [qK]_qj * rotated(sx) + e   (rot_key.cpp:99-117)
+    yell::ops::muladd muladd;
+    const T qK = yell::params::P[context::index_sp_prime(0)];
+    for (size_t j = 0; j < L; ++j) {
+      poly_t *beta_ = get_beta_at(j);
+      const poly_t *alpha_ = get_alpha_at(j);
+      beta_->set(context::gauss_struct(&context::fg_prng));
+      beta_->forward();
+      beta_->add_product_of(*alpha_, ext_sx);
+      beta_->negate();
+      const T qK_j = qK % yell::params::P[j];
+      auto b = beta_->ptr_at(j);
+      auto s = rotated_sx.cptr_at(j);
+      for (size_t d = 0; d < degree; ++d) b[d] = muladd(b[d], s[d], qK_j, j);
+    }
+    rotated_sx.clear(); ext_sx.clear();
+  }
+  MixedRotKey(MixedRotKey const &) = delete; MixedRotKey(MixedRotKey &&) = delete; MixedRotKey &operator=(MixedRotKey const &) = delete;
+  const poly_t *get_beta_at(size_t j) const { return &beta.at(j); }
+  const poly_t *get_alpha_at(size_t j) const { return &alpha.at(j); }
+  poly_t *get_beta_at(size_t j) { return &beta.at(j); }
+  poly_t *get_alpha_at(size_t j) { return &alpha.at(j); }
+  ~MixedRotKey() {}
 };
 
 template <class RotKeyType> struct RotKeySet {

@@ -84,6 +84,18 @@ int main(int argc, char **argv) {
     fHE::context::poly_t dec_rot(L);
     decryptor.decrypt(&dec_rot, rot, sk);
 
+    // MixedRotKey variant, and an arbitrary offset through a RotKeySet (3 = 1 + 2)
+    fHE::MixedRotKey mkey_rot(sk, 1, fHE::MixedRotKey::Direction::LEFT);
+    fHE::Cipher rotm(in_a);
+    if (!evaluator.rotate_slots(&rotm, mkey_rot)) { std::fprintf(stderr, "rotate_slots(MixedRotKey) failed\n"); return 10; }
+    fHE::context::poly_t dec_rotm(L);
+    decryptor.decrypt(&dec_rotm, rotm, sk);
+    fHE::RotKeySet<fHE::RotKey> rset(sk);
+    fHE::Cipher rot3(in_a);
+    if (!evaluator.rotate_slots(&rot3, 3, rset)) { std::fprintf(stderr, "rotate_slots(offset) failed\n"); return 11; }
+    fHE::context::poly_t dec_rot3(L);
+    decryptor.decrypt(&dec_rot3, rot3, sk);
+
     FILE *f = std::fopen(path, "wb");
     if (!f) { std::perror("fopen"); return 9; }
     uint64_t hdr[4] = {logN, L, K, rkey.galois};
@@ -95,6 +107,8 @@ int main(int argc, char **argv) {
     dump(f, "mul_bx", ca.bx); dump(f, "mul_ax", ca.ax); dump(f, "dec_mul", dec_mul);
     dump(f, "rot_bx", rot.bx); dump(f, "rot_ax", rot.ax); dump(f, "dec_rot", dec_rot);
     dump(f, "msg_a", ma); dump(f, "msg_b", mb);
+    for (size_t j = 0; j < L; ++j) { dump(f, "xk_beta", *mkey_rot.get_beta_at(j)); dump(f, "xk_alpha", *mkey_rot.get_alpha_at(j)); }
+    dump(f, "rotm_bx", rotm.bx); dump(f, "rotm_ax", rotm.ax); dump(f, "dec_rotm", dec_rotm); dump(f, "dec_rot3", dec_rot3);
     std::fclose(f);
     std::printf("host_roundtrip OK\n");
     return 0;

@@ -56,6 +56,11 @@ def test_config1_roundtrip_through_cpp_api(tmp_path, logN, L, K):
     assert galois == o.rotation_galois(1)
     assert np.array_equal(d["rot_bx"][0], rb) and np.array_equal(d["rot_ax"][0], ra)
     assert np.array_equal(d["dec_rot"][0], o.decrypt(rb, ra, sx))
+    # MixedRotKey path through the C++ API
+    xb, xa = np.stack(d["xk_beta"]), np.stack(d["xk_alpha"])
+    mb_, ma_ = o.rotate_mixed(a_bx, a_ax, galois, xb, xa)
+    assert np.array_equal(d["rotm_bx"][0], mb_) and np.array_equal(d["rotm_ax"][0], ma_)
+    assert np.array_equal(d["dec_rotm"][0], o.decrypt(mb_, ma_, sx))
     # the keys the C++ side generated are valid: decrypt(rot) is the rotated message up to noise on limb 0
     p0 = int(o.primes[0])
     msg = d["msg_a"][0][0]
@@ -64,3 +69,10 @@ def test_config1_roundtrip_through_cpp_api(tmp_path, logN, L, K):
     diff = np.minimum(diff, p0 - diff)
     if K >= L:  # hybrid key switching is only low-noise when P >= Q (the reference fixes K = L, context.hpp:10)
         assert int(diff.max()) < 1 << 30 and msg.any()
+    # MixedRotKey and RotKeySet results decrypt to the rotated message as well (offset 3 = galois 27)
+    dm = (d["dec_rotm"][0][0].astype(object) - want.astype(object)) % p0
+    assert int(np.minimum(dm, p0 - dm).max()) < 1 << 30
+    if K >= L:
+        want3 = o.apply_galois_non_ntt(d["msg_a"][0].copy(), o.rotation_galois(3))[0]
+        d3 = (d["dec_rot3"][0][0].astype(object) - want3.astype(object)) % p0
+        assert int(np.minimum(d3, p0 - d3).max()) < 1 << 30
