@@ -161,7 +161,6 @@ def main():
         return torch.randint(0, 1 << 61, shape, dtype=torch.int64, device="cuda", generator=gen)
 
     inputs = {"primes": primes, "psi": psi}
-    dominant = None
     if args.workload in ("c3", "c5"):
         c0, c1 = rnd(B, 2, Li, N), rnd(B, 2, Li, N)
         beta, alpha = rnd(L, L, N), rnd(L, L, N)
@@ -169,7 +168,6 @@ def main():
         ctx.load_mult_key(beta, alpha)
         step = lambda: ctx.mul_relin_rescale(out, c0, c1, Li, batch=B)  # noqa: E731
         metric, unit = "ct-mult+relin+rescale/sec at N=2^%d, Li=%d" % (logN, Li), "ops/s"
-        dominant = ("ntt_fwd_cols", "ntt_fwd_rows")
     elif args.workload == "c4":
         ct = rnd(B, 2, Li, N)
         rkb, rka = rnd(L + K, N), rnd(L + K, N)
@@ -178,7 +176,6 @@ def main():
         work = ct.clone()
         step = lambda: ctx.rotate(galois, work, Li, batch=B)  # noqa: E731
         metric, unit = "rotation-keyswitch/sec at N=2^%d, Li=K=%d" % (logN, Li), "ops/s"
-        dominant = ("bconv_modup", "bconv_moddown")
     else:
         x = rnd(B, N)
         idx = np.tile(np.arange(L, dtype=np.uint32), (B + L - 1) // L)[:B]
@@ -191,7 +188,6 @@ def main():
             step = lambda: ctx.ntt_forward(x, idx)  # noqa: E731
             per_step_units = B
         metric, unit = "limb-NTTs/sec at N=2^%d" % logN, "limb-NTT/s"
-        dominant = ("ntt_fwd_cols", "ntt_fwd_rows")
     units_per_step = B if args.workload in ("c3", "c4", "c5") else per_step_units
 
     def barrier():
@@ -219,37 +215,41 @@ def main():
     value = units_per_step * args.steps * world / elapsed
     alg = algorithmic_bytes(args.workload, N, Li, K)
 
-    # roofline of the dominant kernel (pair): algorithmic bytes per launch / average launch duration,
-    # durations from HIP events recorded on the launch stream inside the timed region.
+    # roofline of the dominant kernel: algorithmic bytes per launch / average launch duration, durations from HIP
+    # events recorded on the launch stream inside the timed region (fhe_hip_profile_*).
+    #  - c3 / c5: relin_rows_mac_kernel (row pass of the Li^2 digit NTTs fused with the key MAC): per ciphertext it
+    #    reads 2*Li^2 key limbs + the Li limbs of ct[2] + the 2*Li addend limbs and writes 2*Li limbs.
+    #  - ntt / c2: the forward cols+rows kernel pair = one limb-NTT = 16*N bytes.
+    #  - c4: the two base-conversion kernels, Li (or K) limbs in, K (or Li) limbs out per conversion.
     roofline = None
-    if dominant:
-        ms = sum(prof.get(k, (0, 0.0))[1] for k in dominant)
-        launches = max(prof.get(k, (0, 0.0))[0] for k in dominant) if any(k in prof for k in dominant) else 0
-        if launches and ms > 0:
-            if dominant[0].startswith("ntt"):
-                # every limb-NTT is one cols + one rows pass; count limb-NTTs done by these launches in the region
-                if args.workload in ("c3", "c5"):
-                    limb_ntts = (Li * Li + 2 * (Li - 1) + 0) * units_per_step * args.steps  # forward NTTs only
-                else:
-                    limb_ntts = B * args.steps
-                alg_total = limb_ntts * 16 * N
-                kname = "ntt_fwd (cols+rows pair)"
-            else:
-                alg_total = units_per_step * args.steps * 8 * N * (Li + K) * 2  # conversion in/out limbs, informational
-                kname = "+".join(dominant)
-            achieved = alg_total / (ms * 1e-3) / 1e9
-            pair_launches = launches
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                        "alg_bytes_per_launch": alg_total / pair_launches, "avg_launch_ms": ms / pair_launches,
-                        "launches": pair_launches}
+    def kms(name):
+        return prof.get(name, (0, 0.0))
+    if args.workload in ("c3", "c5"):
+        launches, ms = kms("relin_rows_mac")
+        kname = "relin_rows_mac_kernel"
+        alg_total = units_per_step * args.steps * 8 * N * (2 * Li * Li + 5 * Li)
+    elif args.workload == "c4":
+        launches = kms("bconv_modup")[0] + kms("bconv_moddown")[0]
+        ms = kms("bconv_modup")[1] + kms("bconv_moddown")[1]
+        kname = "bconv_kernel (mod-up + 2x mod-down)"
+        alg_total = units_per_step * args.steps * 8 * N * 3 * (Li + K)
+    else:
+        launches = kms("ntt_fwd_cols")[0]
+        ms = kms("ntt_fwd_cols")[1] + kms("ntt_fwd_rows")[1]
+        kname = "ntt_fwd (ntt_cols_kernel + ntt_rows_kernel pair)"
+        alg_total = B * args.steps * 16 * N
+    if launches and ms > 0:
+        achieved = alg_total / (ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if os.path.exists(tpath) and not args.batch:
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "alg_bytes_per_launch": alg_total / launches, "avg_launch_ms": ms / launches, "launches": launches}
 
     result = {
         "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -17,5 +17,9 @@ for wl in c3 ntt; do
   timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$wl -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > $OUT/fetch_$wl.log 2>&1 || { tail -5 $OUT/fetch_$wl.log; exit 1; }
   timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$wl -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > $OUT/write_$wl.log 2>&1 || { tail -5 $OUT/write_$wl.log; exit 1; }
 done
-python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt
-cat $OUT/pmc_summary.txt | head -60
+for wl in c3 ntt; do
+  mkdir -p $OUT/pmc_$wl && cp -r $OUT/fetch_$wl $OUT/write_$wl $OUT/pmc_$wl/ 2>/dev/null
+  python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT/pmc_$wl > $OUT/pmc_summary_$wl.txt
+  rm -rf $OUT/pmc_$wl
+done
+cat $OUT/pmc_summary_c3.txt | head -40
