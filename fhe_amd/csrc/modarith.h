@@ -45,17 +45,8 @@ __device__ __forceinline__ u64 mont_reduce(u64 thi, u64 tlo, const PrimeC &P) {
   }
 }
 
-// a * b * 2^-64 mod p in (0, 2p); a < p (Montgomery-form constant or canonical data), b any 64-bit value.
 template <bool SP>
-__device__ __forceinline__ u64 mont_mul(u64 a, u64 b, const PrimeC &P) {
-  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-  const u64 t0 = mad_wide(a0, b0, 0);
-  const u64 t1 = mad_wide(a0, b1, t0 >> 32);
-  const u64 t2 = mad_wide(a1, b0, (u64)(u32)t1);
-  const u64 thi = mad_wide(a1, b1, (t1 >> 32) + (t2 >> 32));
-  const u64 tlo = (t2 << 32) | (u64)(u32)t0;
-  return mont_reduce<SP>(thi, tlo, P);
-}
+__device__ __forceinline__ u64 mont_mul(u64 a, u64 b, const PrimeC &P);
 
 __device__ __forceinline__ u64 csub(u64 x, u64 m) { return x >= m ? x - m : x; }
 
@@ -78,10 +69,24 @@ __device__ __forceinline__ void mac128(u64 &hi, u64 &lo, u64 a, u64 b) {
   hi += h + (lo < l ? 1 : 0);
 }
 
-// thi - w of the Montgomery product a*b (a < p Montgomery-form constant, b any 64-bit value): a signed value in
-// (-p, p), returned mod 2^64.  mont_mul(a, b) == mont_diff(a, b) + p.
+// v_mad_u64_u32 behind opaque asm: keeps the 64-bit addend inside the multiply-add (the compiler otherwise splits
+// mad(a, b, c) into mul + add and re-associates the carry words through extra v_mov pairs).  The carry-out SGPR pair
+// is a dead dummy, never read.
+__device__ __forceinline__ u64 mad_op0(u32 a, u32 b) {
+  u64 d, cc;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(cc) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ u64 mad_op(u32 a, u32 b, u64 c) {
+  u64 d, cc;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cc) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ u64 pair64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+
+// Reference formulation of mont_diff (kept for tools/ubench/bfly.hip and the generic-prime path).
 template <bool SP>
-__device__ __forceinline__ u64 mont_diff(u64 a, u64 b, const PrimeC &P) {
+__device__ __forceinline__ u64 mont_diff_ref(u64 a, u64 b, const PrimeC &P) {
   const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
   const u64 t0 = mad_wide(a0, b0, 0);
   const u64 t1 = mad_wide(a0, b1, t0 >> 32);
@@ -98,6 +103,90 @@ __device__ __forceinline__ u64 mont_diff(u64 a, u64 b, const PrimeC &P) {
     const u64 tlo = (t2 << 32) | (u64)(u32)t0;
     return thi - __umul64hi(tlo * P.pinv, P.p);
   }
+}
+
+// t2 = a*b + c and the carry out of that 64-bit sum as 0/1 (one asm statement so that the two wait states gfx950
+// needs between a VALU SGPR write and a VALU read of it are inside the statement).
+__device__ __forceinline__ u64 mad_op_carry(u32 a, u32 b, u64 c, u32 &carry) {
+  u64 d, cc;
+  asm("v_mad_u64_u32 %0, %2, %3, %4, %5\n\ts_nop 1\n\tv_cndmask_b32_e64 %1, 0, 1, %2"
+      : "=&v"(d), "=v"(carry), "=&s"(cc)
+      : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+// D = a*b*2^-64 (mod p) as a signed value in (-p, p), returned mod 2^64; a < p (Montgomery-form constant or
+// canonical data, so a1 < 2^30), b <= 2^64 - 2^34 (any lazy value < 4p + 2^32).  For b up to 2^64-1 the upper bound
+// weakens to p + 2^30.   mont_mul(a, b) == mont_diff(a, b) + p.
+//
+// SP form (p = p1*2^32 + 1), word-serial; on gfx950 every VALU instruction except plain 32-bit VOP1/VOP2 ones issues
+// at the rate of v_mad_u64_u32 (tools/ubench/instrate.hip), so the 64-bit additions ride in multiply-add addends:
+//   step 1 (additive):  q0 = -T0 mod 2^32, c0 = (T0 != 0):
+//        V = (T + q0*p) / 2^32 - a1*b1*2^32 = (h0 + c0) + a1*b0 + q0*p1 + a0*b1              (65 bits: V2:V1:V0)
+//   step 2 (subtractive): V - V0*p has a zero low word:  D = a1*b1 + (V2:V1) - V0*p1.
+// 6 multiply-adds + 3 carry-word operations + 3 plain ones (the product-then-reduce form compiles to 6 + 18).
+template <bool SP>
+__device__ __forceinline__ u64 mont_diff(u64 a, u64 b, const PrimeC &P) {
+  if constexpr (SP) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u32 p1 = P.p1;
+    const u64 t0 = mad_op0(a0, b0);
+    const u32 T0 = (u32)t0;
+    const u32 hlo = (u32)(t0 >> 32) + min(T0, 1u);        // h0 <= 2^32 - 2: no carry
+    const u64 t1 = mad_op(a1, b0, pair64(hlo, 0u));       // < 2^62 + 2^32
+    const u64 m = mad_op(0u - T0, p1, t1);                // < 2^63 + 2^32
+    u32 V2, w1, w2;
+    const u64 t2 = mad_op_carry(a0, b1, m, V2);
+    const u32 V0 = (u32)t2, V1 = (u32)(t2 >> 32);
+    const u64 n = mad_op0(V0, p1);
+    const u32 elo = __builtin_subc(V1, (u32)n, 0u, &w1);
+    const u32 ehi = __builtin_subc(V2, (u32)(n >> 32), w1, &w2);
+    return mad_op(a1, b1, pair64(elo, ehi));
+  } else {
+    return mont_diff_ref<false>(a, b, P);
+  }
+}
+
+// a * b * 2^-64 mod p in (0, 2p); a < 2p (Montgomery-form constant or data), b < 4p + 2^32.
+template <bool SP>
+__device__ __forceinline__ u64 mont_mul(u64 a, u64 b, const PrimeC &P) {
+  if constexpr (SP) {
+    return mont_diff<true>(a, b, P) + P.p;
+  } else {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 t0 = mad_wide(a0, b0, 0);
+    const u64 t1 = mad_wide(a0, b1, t0 >> 32);
+    const u64 t2 = mad_wide(a1, b0, (u64)(u32)t1);
+    const u64 thi = mad_wide(a1, b1, (t1 >> 32) + (t2 >> 32));
+    const u64 tlo = (t2 << 32) | (u64)(u32)t0;
+    return mont_reduce<false>(thi, tlo, P);
+  }
+}
+
+// previous candidate (carry words through compiler-visible add/addc chains), kept for tools/ubench/bfly.hip
+__device__ __forceinline__ u64 mont_diff_v1(u64 a, u64 b, const PrimeC &P) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  const u32 p1 = P.p1;
+  const u64 t0 = mad_op0(a0, b0);
+  u32 c, c1, c2, w1, w2;
+  const u32 hlo = __builtin_addc((u32)(t0 >> 32), p1 + 1u, 0u, &c);
+  const u64 t1 = mad_op(a1, b0, pair64(hlo, c));
+  const u64 m = mad_op(~(u32)t0, p1, t1);
+  const u64 t2 = mad_op0(a0, b1);
+  const u32 V0 = __builtin_addc((u32)t2, (u32)m, 0u, &c1);
+  const u32 V1 = __builtin_addc((u32)(t2 >> 32), (u32)(m >> 32), c1, &c2);
+  const u64 n = mad_op0(V0, p1);
+  const u32 elo = __builtin_subc(V1, (u32)n, 0u, &w1);
+  const u32 ehi = __builtin_subc(c2, (u32)(n >> 32), w1, &w2);
+  return mad_op(a1, b1, pair64(elo, ehi));
+}
+
+template <bool SP>
+__device__ __forceinline__ void ct_bfly_ref(u64 &X, u64 &Y, u64 W, const PrimeC &P) {
+  const u64 D = mont_diff_ref<SP>(W, Y, P);
+  const u64 xp = (X >= P.twop) ? X - P.p : X + P.p;
+  X = xp + D;
+  Y = xp - D;
 }
 
 // Harvey lazy Cooley-Tukey butterfly: X, Y in [0,4p) -> (0,4p);  W in Montgomery form.

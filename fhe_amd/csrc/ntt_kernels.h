@@ -87,7 +87,11 @@ constexpr int ROW_LDS = 16 * 18;
 
 template <bool SP, bool INVERSE>
 __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
+#if defined(NTT_ABL) && NTT_ABL == 4
+  __shared__ __attribute__((aligned(16))) u64 lds[32 * ROW_LDS];  // occupancy experiment: 2 workgroups per CU
+#else
   __shared__ __attribute__((aligned(16))) u64 lds[16 * ROW_LDS];
+#endif
   const u32 tid = threadIdx.x, rloc = tid >> 4, t = tid & 15;
   const u32 rows_per_wg = blockDim.x >> 4;
   const u32 row = blockIdx.x * rows_per_wg + rloc;
@@ -278,7 +282,7 @@ struct RelinArgs {
 };
 
 template <bool SP>
-__global__ __launch_bounds__(256) void relin_rows_mac_kernel(RelinArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void relin_rows_mac_kernel(RelinArgs a) {
   __shared__ __attribute__((aligned(16))) u64 lds[16 * ROW_LDS];
   const u32 tid = threadIdx.x, rloc = tid >> 4, t = tid & 15;
   const u32 rows_per_wg = blockDim.x >> 4;

@@ -1,0 +1,90 @@
+// Microbenchmark: register-resident radix-16 Harvey butterfly throughput on gfx950 for candidate
+// Montgomery formulations (checks that they agree bit for bit before timing).
+//   hipcc --offload-arch=gfx950 -O3 -o bfly bfly.hip && ./bfly
+#include "../../fhe_amd/csrc/modarith.h"
+#include <cstdio>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+  fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+
+#ifndef VARIANTS
+#define VARIANTS 3
+#endif
+
+template <int V> __device__ __forceinline__ void bf(u64 &X, u64 &Y, u64 W, const PrimeC &P);
+template <> __device__ __forceinline__ void bf<0>(u64 &X, u64 &Y, u64 W, const PrimeC &P) { ct_bfly_ref<true>(X, Y, W, P); }
+template <> __device__ __forceinline__ void bf<1>(u64 &X, u64 &Y, u64 W, const PrimeC &P) { ct_bfly<true>(X, Y, W, P); }
+// variant 2 = carry words through add/addc chains
+template <> __device__ __forceinline__ void bf<2>(u64 &X, u64 &Y, u64 W, const PrimeC &P) {
+  const u64 D = mont_diff_v1(W, Y, P);
+  const u64 xp = (X >= P.twop) ? X - P.p : X + P.p;
+  X = xp + D;
+  Y = xp - D;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void k(u64 *d, const u64 *w, PrimeC P, int iters) {
+  u64 x[16], tw[15];
+  const size_t base = (size_t)blockIdx.x * 4096 + threadIdx.x;
+  for (int i = 0; i < 16; ++i) x[i] = d[base + 256 * i];
+  for (int i = 0; i < 15; ++i) tw[i] = w[(threadIdx.x & 63) * 15 + i];
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int h = 8 >> s;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (!(i & h)) bf<V>(x[i], x[i + h], tw[(1 << s) - 1 + (i >> (4 - s))], P);
+    }
+  }
+  for (int i = 0; i < 16; ++i) d[base + 256 * i] = x[i];
+}
+
+static u64 mulmod(u64 a, u64 b, u64 p) { return (u64)((unsigned __int128)a * b % p); }
+
+int main() {
+  const u64 p = ((1ull << 30) - 1) * (1ull << 32) + 1;  // modulus shape only; primality is irrelevant here
+  PrimeC P{};
+  P.p = p; P.twop = 2 * p; P.p1 = (u32)(p >> 32);
+  u64 inv = 1; for (int i = 0; i < 6; ++i) inv *= 2 - p * inv; P.pinv = inv;
+  const int nblk = 256 * 8, iters = 512;
+  const size_t n = (size_t)nblk * 4096;
+  std::vector<u64> h(n), w(64 * 15);
+  u64 s = 88172645463325252ull;
+  auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+  for (auto &v : h) v = rnd() % (4 * p > p ? 4 * p : p);
+  for (auto &v : w) v = rnd() % p;
+  // corner cases in the first block
+  h[0] = 0; h[1] = 4 * p - 1; h[2] = 2 * p; h[3] = 2 * p - 1; h[4] = p; w[0] = 0; w[1] = p - 1; w[2] = 1ull << 32; w[3] = 0xffffffffull;
+  u64 *d[VARIANTS], *dw;
+  CHECK(hipMalloc(&dw, w.size() * 8));
+  CHECK(hipMemcpy(dw, w.data(), w.size() * 8, hipMemcpyHostToDevice));
+  std::vector<std::vector<u64>> out(VARIANTS, std::vector<u64>(n));
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  for (int v = 0; v < VARIANTS; ++v) {
+    CHECK(hipMalloc(&d[v], n * 8));
+    for (int rep = 0; rep < 2; ++rep) {
+      CHECK(hipMemcpy(d[v], h.data(), n * 8, hipMemcpyHostToDevice));
+      CHECK(hipEventRecord(e0));
+      if (v == 0) k<0><<<nblk, 256>>>(d[v], dw, P, iters);
+      else if (v == 1) k<1><<<nblk, 256>>>(d[v], dw, P, iters);
+      else k<2><<<nblk, 256>>>(d[v], dw, P, iters);
+      CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+      float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+      const double bf = (double)nblk * 256 * 32 * iters;
+      if (rep) printf("variant %d: %.3f ms  %.3e bfly/s\n", v, ms, bf / (ms * 1e-3));
+    }
+    CHECK(hipMemcpy(out[v].data(), d[v], n * 8, hipMemcpyDeviceToHost));
+  }
+  // both variants are lazy ([0,4p) representatives may differ): compare residues
+  size_t bad = 0;
+  for (size_t i = 0; i < n; ++i) {
+    bool ok = true;
+    for (int v = 1; v < VARIANTS; ++v) ok = ok && out[v][i] < 4 * p && out[0][i] % p == out[v][i] % p;
+    if (out[0][i] >= 4 * p || !ok) { if (bad < 5) printf("mismatch %zu: %llx %llx\n", i, out[0][i], out[1][i]); ++bad; }
+  }
+  printf("mismatches: %zu\n", bad);
+  (void)mulmod;
+  return bad != 0;
+}
