@@ -90,6 +90,68 @@ def test_ntt_accepts_foreign_residues_and_edge_values():
     assert not host(dz).any()
 
 
+def _word_edge_patterns(p, N, seed):
+    """Inputs that drive the word-serial Montgomery steps through their carry / zero-word corners."""
+    rng = np.random.default_rng(seed)
+    m32 = (1 << 32) - 1
+    specials = np.array([0, 1, 2, m32, 1 << 32, (1 << 32) + 1, p - 1, p - 2, p >> 1, (p >> 32) << 32, ((p >> 32) << 32) - 1,
+                         p - (1 << 32), p & ~m32 | 0, (p - 1) & ~m32, m32 << 30], dtype=np.uint64) % np.uint64(p)
+    rows = []
+    rows.append(np.resize(specials, N))                                                   # corner values cycled
+    rows.append((rng.integers(0, p >> 32, N, dtype=np.uint64) << np.uint64(32)))          # low word zero everywhere
+    rows.append(rng.integers(0, 1 << 32, N, dtype=np.uint64))                             # high word zero everywhere
+    rows.append((rng.integers(0, p >> 32, N, dtype=np.uint64) << np.uint64(32)) | np.uint64(m32))  # low word all ones
+    rows.append(np.full(N, p - 1, np.uint64))                                             # constant p-1
+    rows.append(np.where(rng.integers(0, 2, N) == 1, np.uint64(p - 1), np.uint64(0)))     # 0 / p-1 mix
+    return np.stack(rows)
+
+
+@pytest.mark.parametrize("logN,sp", [(10, True), (13, True), (16, True), (12, False)])
+def test_ntt_word_edge_patterns(logN, sp):
+    o, g = ctx_pair(logN, 3, 2, sp)
+    for m in (0, 4):
+        p = int(o.primes[m])
+        x = _word_edge_patterns(p, o.N, 100 + m)
+        idx = [m] * x.shape[0]
+        want = o.ntt_forward(x.copy(), idx)
+        d = dev(x)
+        g.ntt_forward(d, idx)
+        assert np.array_equal(host(d), want)
+        g.ntt_backward(d, idx)
+        assert np.array_equal(host(d), x)
+        want_b = o.ntt_backward(x.copy(), idx)
+        d = dev(x)
+        g.ntt_backward(d, idx)
+        assert np.array_equal(host(d), want_b)
+        # forward input bound of the C-ABI: any value < 4p
+        hi = x + np.uint64(3 * p)
+        want_hi = o.ntt_forward(hi.copy(), idx)
+        d = dev(hi)
+        g.ntt_forward(d, idx)
+        assert np.array_equal(host(d), want_hi)
+
+
+def test_pointwise_word_edge_patterns():
+    """multiply_plain / cross_mult on the same corner patterns (zero low words, p-1, 2^32 multiples)."""
+    o, g = ctx_pair(10, 3, 2)
+    Li = 3
+    a = np.stack([_word_edge_patterns(int(o.primes[l]), o.N, 7 + l) for l in range(Li)], axis=1)  # [6][Li][N]
+    b = a[::-1].copy()
+    c0 = a.reshape(3, 2, Li, o.N)
+    c1 = b.reshape(3, 2, Li, o.N)
+    for k in range(3):
+        for pt in (b[2 * k], b[2 * k + 1]):
+            wb, wa = o.multiply_plain(c0[k, 0], c0[k, 1], np.ascontiguousarray(pt))
+            d = dev(c0[k].copy())
+            g.multiply_plain(d, dev(np.ascontiguousarray(pt)), Li, 1)
+            assert np.array_equal(host(d)[0], wb) and np.array_equal(host(d)[1], wa)
+        want = o.cross_mult(c0[k, 0].copy(), c0[k, 1].copy(), c1[k, 0].copy(), c1[k, 1].copy())
+        out = torch.zeros((3, Li, o.N), dtype=torch.int64, device="cuda")
+        g.cross_mult(out, dev(c0[k].copy()), dev(c1[k].copy()), Li, 1)
+        for h in range(3):
+            assert np.array_equal(host(out)[h], want[h])
+
+
 def test_ntt_host_memory_kind():
     o, g = ctx_pair(12, 3, 2)
     idx = [1, 3]

@@ -9,16 +9,47 @@
   fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
 
 #ifndef VARIANTS
-#define VARIANTS 3
+#define VARIANTS 4
 #endif
 
 template <int V> __device__ __forceinline__ void bf(u64 &X, u64 &Y, u64 W, const PrimeC &P);
 template <> __device__ __forceinline__ void bf<0>(u64 &X, u64 &Y, u64 W, const PrimeC &P) { ct_bfly_ref<true>(X, Y, W, P); }
 template <> __device__ __forceinline__ void bf<1>(u64 &X, u64 &Y, u64 W, const PrimeC &P) { ct_bfly<true>(X, Y, W, P); }
-// variant 2 = carry words through add/addc chains
+// variant 2 = variant 1 with the 2p reduction of X decided on the high word by plain 32-bit VOP2 operations
+// (values then live in [0, 4p + 2^32))
+__device__ __forceinline__ u64 xp_fast(u64 X, const PrimeC &P) {
+  const int dd = (int)(2u * P.p1 - (u32)(X >> 32));  // < 0  <=>  X.hi > 2*p1  =>  subtract p, else add p
+  const u32 mask = (u32)(dd >> 31);
+  return X + pair64(mask | 1u, P.p1 ^ mask);
+}
 template <> __device__ __forceinline__ void bf<2>(u64 &X, u64 &Y, u64 W, const PrimeC &P) {
-  const u64 D = mont_diff_v1(W, Y, P);
-  const u64 xp = (X >= P.twop) ? X - P.p : X + P.p;
+  const u64 D = mont_diff<true>(W, Y, P);
+  const u64 xp = xp_fast(X, P);
+  X = xp + D;
+  Y = xp - D;
+}
+// variant 3 = variant 2 with q0 / c0 through plain VOP2 operations
+__device__ __forceinline__ u64 mont_diff_v3(u64 a, u64 b, const PrimeC &P) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  const u32 p1 = P.p1;
+  const u64 t0 = mad_op0(a0, b0);
+  const u32 T0 = (u32)t0;
+  u32 c0;
+  asm("v_min_u32 %0, 1, %1" : "=v"(c0) : "v"(T0));
+  const u32 hlo = (u32)(t0 >> 32) + c0;
+  const u64 t1 = mad_op(a1, b0, pair64(hlo, 0u));
+  const u64 m = mad_op(0u - T0, p1, t1);
+  u32 V2, w1, w2;
+  const u64 t2 = mad_op_carry(a0, b1, m, V2);
+  const u32 V0 = (u32)t2, V1 = (u32)(t2 >> 32);
+  const u64 n = mad_op0(V0, p1);
+  const u32 elo = __builtin_subc(V1, (u32)n, 0u, &w1);
+  const u32 ehi = __builtin_subc(V2, (u32)(n >> 32), w1, &w2);
+  return mad_op(a1, b1, pair64(elo, ehi));
+}
+template <> __device__ __forceinline__ void bf<3>(u64 &X, u64 &Y, u64 W, const PrimeC &P) {
+  const u64 D = mont_diff_v3(W, Y, P);
+  const u64 xp = xp_fast(X, P);
   X = xp + D;
   Y = xp - D;
 }
@@ -69,7 +100,8 @@ int main() {
       CHECK(hipEventRecord(e0));
       if (v == 0) k<0><<<nblk, 256>>>(d[v], dw, P, iters);
       else if (v == 1) k<1><<<nblk, 256>>>(d[v], dw, P, iters);
-      else k<2><<<nblk, 256>>>(d[v], dw, P, iters);
+      else if (v == 2) k<2><<<nblk, 256>>>(d[v], dw, P, iters);
+      else k<3><<<nblk, 256>>>(d[v], dw, P, iters);
       CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
       float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
       const double bf = (double)nblk * 256 * 32 * iters;
@@ -81,7 +113,7 @@ int main() {
   size_t bad = 0;
   for (size_t i = 0; i < n; ++i) {
     bool ok = true;
-    for (int v = 1; v < VARIANTS; ++v) ok = ok && out[v][i] < 4 * p && out[0][i] % p == out[v][i] % p;
+    for (int v = 1; v < VARIANTS; ++v) ok = ok && out[v][i] < 4 * p + (1ull << 32) && out[0][i] % p == out[v][i] % p;
     if (out[0][i] >= 4 * p || !ok) { if (bad < 5) printf("mismatch %zu: %llx %llx\n", i, out[0][i], out[1][i]); ++bad; }
   }
   printf("mismatches: %zu\n", bad);
