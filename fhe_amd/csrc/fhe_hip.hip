@@ -398,7 +398,9 @@ int get_galois_perm(fhe_hip_ctx *c, u64 galois, u32 **perm) {
 }
 
 // rotate_slots_inplace + apply_rotation_key (evaluator.cpp:299-311, 343-399); ct = [b][2][Li][N] in place
-int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch) {
+// non_ntt = Evaluator::Impl::rotate_slots_inplace_non_ntt + apply_rotation_key_non_ntt (src/evaluator.cpp:327-339, 520-574): ct in the
+// power basis; reproduced literally, including approximated_mod_down adding its NTT-domain correction to power-basis limbs.
+int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_ntt = false) {
   const u64 N = c->N; const u32 K = c->K, nl = Li + K;
   auto it = c->rot_keys.find(galois);
   if (it == c->rot_keys.end()) FAIL(c, FHE_HIP_ERR_NOKEY, "rotation key not loaded for this galois element");
@@ -412,27 +414,43 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch) {
   u64 *g = (u64 *)c->ws[3], *e0 = (u64 *)c->ws[4], *e1 = (u64 *)c->ws[5], *pw = (u64 *)c->ws[0];
   if (identity) {
     HIPCHK(c, hipMemcpyAsync(g, ct, ctb, hipMemcpyDeviceToDevice, c->stream));
+  } else if (non_ntt) {
+    LAUNCH(c, "galois_coeff", galois_coeff_kernel, dim3((unsigned)(N / PW_THREADS), 2 * Li, batch), dim3(PW_THREADS), g, (const u64 *)ct,
+           (const PrimeC *)c->d_primes, c->logN, galois, Li);
   } else {
     TRY(get_galois_perm(c, galois, &perm));
     LAUNCH(c, "galois_gather", galois_gather_kernel, dim3((unsigned)(N / PW_THREADS), 2 * Li, batch), dim3(PW_THREADS), g, (const u64 *)ct,
            (const u32 *)perm, N);
   }
-  // power basis of ax_g (d[1]->backward(), :360)
-  NttPlan pi{g + (size_t)Li * N, pw, c->d_iota, 1, Li, Li, Li, batch, (u64)2 * Li * N, (u64)Li * N};
-  TRY(ntt_run(c, pi, true));
-  // mod up: special limbs from the power basis; normal limbs of the NTT-domain result are ax_g itself
-  // (NTT(INTT(x)) = x for canonical x, so the Li forward NTTs of :363-366 are not recomputed)
-  TRY(dev_conv_to_special(c, e0, nl, Li, pw, Li, Li, batch));
-  for (u32 b = 0; b < batch; ++b)
-    HIPCHK(c, hipMemcpyAsync(e0 + (size_t)b * nl * N, g + ((size_t)b * 2 + 1) * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream));
-  {  // forward NTT of the K special limbs
+  if (non_ntt) {
+    // ax_g is already in the power basis (:537): mod up, then forward NTT of all Li+K limbs (:539-542)
+    TRY(dev_conv_to_special(c, e0, nl, Li, g + (size_t)Li * N, 2 * Li, Li, batch));
+    for (u32 b = 0; b < batch; ++b)
+      HIPCHK(c, hipMemcpyAsync(e0 + (size_t)b * nl * N, g + ((size_t)b * 2 + 1) * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream));
+    NttPlan pf{e0, e0, c->d_rotmap + (size_t)Li * c->M, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
+    TRY(ntt_run(c, pf, false));
+  } else {
+    // power basis of ax_g (d[1]->backward(), :360)
+    NttPlan pi{g + (size_t)Li * N, pw, c->d_iota, 1, Li, Li, Li, batch, (u64)2 * Li * N, (u64)Li * N};
+    TRY(ntt_run(c, pi, true));
+    // mod up: special limbs from the power basis; normal limbs of the NTT-domain result are ax_g itself
+    // (NTT(INTT(x)) = x for canonical x, so the Li forward NTTs of :363-366 are not recomputed)
+    TRY(dev_conv_to_special(c, e0, nl, Li, pw, Li, Li, batch));
+    for (u32 b = 0; b < batch; ++b)
+      HIPCHK(c, hipMemcpyAsync(e0 + (size_t)b * nl * N, g + ((size_t)b * 2 + 1) * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream));
+    // forward NTT of the K special limbs
     NttPlan pf{e0 + (size_t)Li * N, e0 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
     TRY(ntt_run(c, pf, false));
   }
   const u32 *rotmap = c->d_rotmap + (size_t)Li * c->M;
   LAUNCH_SP(c, "rot_keymul", rot_keymul_kernel, pw_grid(c, nl, batch), dim3(PW_THREADS), e0, e1, (const u64 *)e0, (const u64 *)it->second.beta_m,
             (const u64 *)it->second.alpha_m, (const PrimeC *)c->d_primes, rotmap, nl, N);
-  {  // special limbs back to the power basis (:386-392)
+  if (non_ntt) {  // every limb back to the power basis (:563-567)
+    NttPlan p0{e0, e0, c->d_rotmap + (size_t)Li * c->M, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
+    TRY(ntt_run(c, p0, true));
+    NttPlan p1{e1, e1, c->d_rotmap + (size_t)Li * c->M, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
+    TRY(ntt_run(c, p1, true));
+  } else {  // special limbs back to the power basis (:386-392)
     NttPlan p0{e0 + (size_t)Li * N, e0 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
     TRY(ntt_run(c, p0, true));
     NttPlan p1{e1 + (size_t)Li * N, e1 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
@@ -658,7 +676,7 @@ static int galois_api(fhe_hip_ctx *c, uint64_t *polys, uint32_t nlimbs, uint64_t
     TRY(get_galois_perm(c, galois, &perm));
     LAUNCH(c, "galois_gather", galois_gather_kernel, grid, dim3(PW_THREADS), d, (const u64 *)tmp, (const u32 *)perm, c->N);
   } else {
-    LAUNCH(c, "galois_coeff", galois_coeff_kernel, grid, dim3(PW_THREADS), d, (const u64 *)tmp, (const PrimeC *)c->d_primes, c->logN, galois);
+    LAUNCH(c, "galois_coeff", galois_coeff_kernel, grid, dim3(PW_THREADS), d, (const u64 *)tmp, (const PrimeC *)c->d_primes, c->logN, galois, nlimbs);
   }
   return st.finish();
 }
@@ -833,7 +851,7 @@ int fhe_hip_mul_relin_rescale(fhe_hip_ctx *c, uint64_t *out, const uint64_t *c0,
   return st.finish();
 }
 
-int fhe_hip_rotate(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind) {
+static int rotate_api(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind, bool non_ntt) {
   TRY(check_ctx(c));
   if (!ct) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   if (galois == 0) return FHE_HIP_OK;  // evaluator.cpp:303-304
@@ -844,8 +862,14 @@ int fhe_hip_rotate(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, s
   Staged st(c, mem_kind);
   u64 *d = nullptr;
   TRY(st.out(ct, batch * 2 * Li * c->N * 8, &d, true));
-  TRY(dev_rotate(c, galois, d, Li, (u32)batch));
+  TRY(dev_rotate(c, galois, d, Li, (u32)batch, non_ntt));
   return st.finish();
+}
+int fhe_hip_rotate(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind) {
+  return rotate_api(c, galois, ct, Li, batch, mem_kind, false);
+}
+int fhe_hip_rotate_non_ntt(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind) {
+  return rotate_api(c, galois, ct, Li, batch, mem_kind, true);
 }
 
 int fhe_hip_load_mixed_rot_key(fhe_hip_ctx *c, uint64_t galois, const uint64_t *beta, const uint64_t *alpha, int mem_kind) {

@@ -178,14 +178,14 @@ __global__ void galois_perm_kernel(u32 *perm, u32 logN, u64 galois) {
 }
 // fHE::apply_galois_non_ntt (src/yell.cpp:41-52): scatter with sign flip; limb k uses modulus k; out-of-place.
 __global__ __launch_bounds__(PW_THREADS) void galois_coeff_kernel(u64 *dst, const u64 *src, const PrimeC *primes, u32 logN,
-                                                                  u64 galois) {
+                                                                  u64 galois, u32 mper) {
   const u64 N = 1ull << logN;
   const u64 d = (u64)blockIdx.x * PW_THREADS + threadIdx.x;
   const u32 cm = blockIdx.y;
   const u64 o = ((u64)blockIdx.z * gridDim.y + cm) * N;
   const u64 raw = d * galois;
   const u64 t = src[o + d];
-  const u64 p = primes[cm].p;
+  const u64 p = primes[cm % mper].p;  // limb cm of a [..][mper][N] stack lives under prime cm % mper
   dst[o + (raw & (N - 1))] = ((raw >> logN) & 1) ? (t > 0 ? p - t : 0) : t;
 }
 

@@ -76,6 +76,7 @@ def load_library():
         "fhe_hip_relinearize": (i, [vp, vp, vp, u32, sz, i]),
         "fhe_hip_mul_relin_rescale": (i, [vp, vp, vp, vp, u32, sz, i]),
         "fhe_hip_rotate": (i, [vp, u64, vp, u32, sz, i]),
+        "fhe_hip_rotate_non_ntt": (i, [vp, u64, vp, u32, sz, i]),
         "fhe_hip_load_mixed_rot_key": (i, [vp, u64, vp, vp, i]),
         "fhe_hip_rotate_mixed": (i, [vp, u64, vp, u32, sz, i]),
         "fhe_hip_decrypt": (i, [vp, vp, vp, vp, u32, sz, i]),
@@ -96,7 +97,7 @@ EXPORTED_SYMBOLS = [
     "fhe_hip_ntt_forward", "fhe_hip_ntt_backward", "fhe_hip_apply_galois", "fhe_hip_apply_galois_non_ntt",
     "fhe_hip_mod_up", "fhe_hip_mod_down", "fhe_hip_rescale", "fhe_hip_load_mult_key", "fhe_hip_load_rot_key",
     "fhe_hip_add", "fhe_hip_multiply_plain", "fhe_hip_cross_mult", "fhe_hip_relin_only", "fhe_hip_relinearize",
-    "fhe_hip_mul_relin_rescale", "fhe_hip_rotate", "fhe_hip_load_mixed_rot_key", "fhe_hip_rotate_mixed", "fhe_hip_decrypt", "fhe_hip_encrypt", "fhe_hip_profile_enable", "fhe_hip_profile_reset",
+    "fhe_hip_mul_relin_rescale", "fhe_hip_rotate", "fhe_hip_rotate_non_ntt", "fhe_hip_load_mixed_rot_key", "fhe_hip_rotate_mixed", "fhe_hip_decrypt", "fhe_hip_encrypt", "fhe_hip_profile_enable", "fhe_hip_profile_reset",
     "fhe_hip_profile_get",
 ]
 
@@ -244,6 +245,12 @@ class HipContext:
     def rotate(self, galois, ct, Li, batch=1):
         (c,), kind = _same_kind(ct)
         self._chk(self.lib.fhe_hip_rotate(self.h, galois, c, Li, batch, kind))
+        return ct
+
+    def rotate_non_ntt(self, galois, ct, Li, batch=1):
+        """Evaluator::rotate_slots_non_ntt (src/evaluator.cpp:138-146, 327-339, 520-574): ct in the power basis, in place."""
+        (c,), kind = _same_kind(ct)
+        self._chk(self.lib.fhe_hip_rotate_non_ntt(self.h, galois, c, Li, batch, kind))
         return ct
 
     # ---- MixedRotKey variant (SURVEY §8(f) rank 1) -----------------------------------------

@@ -4,10 +4,10 @@
 #pragma once
 #include "fHE/base_converter.hpp"
 #include "fHE/cipher.hpp"
+#include "fHE/encoder.hpp"
 #include "fHE/mult_key.hpp"
 #include "fHE/rot_key.hpp"
 namespace fHE {
-struct Encoder;
 struct Evaluator {
  private:
   std::shared_ptr<Encoder> encoder;
@@ -32,6 +32,24 @@ struct Evaluator {
     if (it != loaded_rkeys_.end() && it->second == &rkey) return true;
     if (fhe_hip_load_rot_key(ctx(), rkey.galois, rkey.beta.cptr_at(0), rkey.alpha.cptr_at(0), FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
     loaded_rkeys_[rkey.galois] = &rkey;
+    return true;
+  }
+
+  bool rotate_with(Cipher *rop, RotKey const &rkey, bool non_ntt) const {
+    if (!rop) return false;
+    if (!rop->canonical()) { std::cerr << "Can only rotate canonical ciphertext, call relinearize first." << std::endl; return false; }
+    if (rkey.galois == 0) return true;
+    const size_t Li = rop->moduli_count(), N = context::degree, limbs = Li * N;
+    if (Li > context::nr_ctxt_moduli) throw std::invalid_argument("Too many moduli.");
+    if (Li <= 1) throw std::invalid_argument("nmoduli <= 1");
+    if (!ensure_rot_key(rkey)) return false;
+    std::vector<T> ct(2 * limbs);
+    pack(ct, 0, rop->bx, Li); pack(ct, limbs, rop->ax, Li);
+    const int rc = non_ntt ? fhe_hip_rotate_non_ntt(ctx(), rkey.galois, ct.data(), (uint32_t)Li, 1, FHE_HIP_MEM_HOST)
+                           : fhe_hip_rotate(ctx(), rkey.galois, ct.data(), (uint32_t)Li, 1, FHE_HIP_MEM_HOST);
+    if (rc != FHE_HIP_OK) return false;
+    std::memcpy(rop->bx.ptr_at(0), ct.data(), limbs * sizeof(T));
+    std::memcpy(rop->ax.ptr_at(0), ct.data() + limbs, limbs * sizeof(T));
     return true;
   }
 
@@ -118,21 +136,10 @@ struct Evaluator {
   }
 
   //! The rotation offset is specified in the RotKey (evaluator.cpp:128-136, 299-311, 343-399).
-  bool rotate_slots(Cipher *rop, RotKey const &rkey) const {
-    if (!rop) return false;
-    if (!rop->canonical()) { std::cerr << "Can only rotate canonical ciphertext, call relinearize first." << std::endl; return false; }
-    if (rkey.galois == 0) return true;
-    const size_t Li = rop->moduli_count(), N = context::degree, limbs = Li * N;
-    if (Li > context::nr_ctxt_moduli) throw std::invalid_argument("Too many moduli.");
-    if (Li <= 1) throw std::invalid_argument("nmoduli <= 1");
-    if (!ensure_rot_key(rkey)) return false;
-    std::vector<T> ct(2 * limbs);
-    pack(ct, 0, rop->bx, Li); pack(ct, limbs, rop->ax, Li);
-    if (fhe_hip_rotate(ctx(), rkey.galois, ct.data(), (uint32_t)Li, 1, FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
-    std::memcpy(rop->bx.ptr_at(0), ct.data(), limbs * sizeof(T));
-    std::memcpy(rop->ax.ptr_at(0), ct.data() + limbs, limbs * sizeof(T));
-    return true;
-  }
+  bool rotate_slots(Cipher *rop, RotKey const &rkey) const { return rotate_with(rop, rkey, false); }
+  //! Same on a power-basis ciphertext (evaluator.cpp:138-146, 327-339, 520-574); the device call reproduces the
+  //! reference's arithmetic for this path literally (see include/fhe_hip.h).
+  bool rotate_slots_non_ntt(Cipher *rop, RotKey const &rkey) const { return rotate_with(rop, rkey, true); }
 
   //! MixedRotKey variant (evaluator.cpp:148-156, 313-325, 403-516)
   bool rotate_slots(Cipher *rop, MixedRotKey const &rkey) const {
@@ -171,6 +178,49 @@ struct Evaluator {
         rotate_slots(rop, *rotkey);
       }
     }
+    return true;
+  }
+  //! evaluator.cpp:210-232 (no sign handling there: |offset| mod nr_slots)
+  template <class RotKeyT> bool rotate_slots_non_ntt(Cipher *rop, int offset, RotKeySet<RotKeyT> const &rkeys) const {
+    if (!rop) return false;
+    if (!rop->canonical()) { std::cerr << "Can only rotate canonical ciphertext, call relinearize first." << std::endl; return false; }
+    const size_t nr_slots = context::degree >> 1u;
+    offset = std::abs(offset) % (int)nr_slots;
+    if (offset == 0) return true;
+    const int steps = (int)(std::log2((double)offset) + 1);
+    for (int i = 0; i < steps; ++i) {
+      if (offset & (1 << i)) {
+        RotKeyT const *rotkey = rkeys.get((uint16_t)(1 << i));
+        if (!rotkey) { std::cerr << "No such rotation key for offset " << (1 << i) << "\n"; return false; }
+        rotate_slots_non_ntt(rop, *rotkey);
+      }
+    }
+    return true;
+  }
+
+  //! Replicate the slot at [pos] into every slot: one masking and log2(N/2) rotate-and-adds above the power basis
+  //! (evaluator.cpp:234-267).
+  template <class RotKeyT> bool replicate(Cipher *rop, size_t pos, RotKeySet<RotKeyT> const &rkeys) const {
+    if (!rop || !encoder) return false;
+    if (!rop->canonical()) { std::cerr << "Can only replicate canonical ciphertext, call relinearize first." << std::endl; return false; }
+    const size_t nr_slots = context::degree >> 1, logn = yell::runtime::get().logn - 1;
+    pos %= nr_slots;
+    std::vector<double> mask(nr_slots, 0.);
+    mask[pos] = 1.;
+    const double scale = context::encoder_scale / 8.;
+    context::poly_t mask_poly(rop->moduli_count());
+    encoder->encode(&mask_poly, mask, scale);
+    mask_poly.forward_lazy();
+    multiply_plain(rop, mask_poly, scale);
+    rop->bx.backward();
+    rop->ax.backward();
+    for (size_t i = 0; i < logn; ++i) {
+      fHE::Cipher tmp(*rop);
+      rotate_slots_non_ntt(&tmp, 1 << i, rkeys);
+      add(rop, tmp);  // add is also ok on the power-basis.
+    }
+    rop->bx.forward();
+    rop->ax.forward();
     return true;
   }
 };

@@ -7,6 +7,7 @@
 #include "fHE/context.hpp"
 #include "fHE/cipher.hpp"
 #include "fHE/decryptor.hpp"
+#include "fHE/encoder.hpp"
 #include "fHE/encryptor.hpp"
 #include "fHE/evaluator.hpp"
 
@@ -32,7 +33,8 @@ int main(int argc, char **argv) {
     fHE::RotKey rkey(sk, 1, fHE::RotKey::Direction::LEFT);
     fHE::Encryptor encryptor;
     fHE::Decryptor decryptor;
-    fHE::Evaluator evaluator;
+    auto encoder = std::make_shared<fHE::Encoder>();
+    fHE::Evaluator evaluator(encoder);
 
     // integer plaintexts a, b with small coefficients times 2^40
     fHE::context::poly_t ma(L), mb(L);
@@ -96,6 +98,30 @@ int main(int argc, char **argv) {
     fHE::context::poly_t dec_rot3(L);
     decryptor.decrypt(&dec_rot3, rot3, sk);
 
+    // Encoder (reference main.cpp:27-31 style values 1.0 + i) and the power-basis rotation / replicate composites
+    const size_t nr_slots = N >> 1;
+    std::vector<double> vals(nr_slots);
+    for (size_t i = 0; i < nr_slots; ++i) vals[i] = 1.0 + (double)(i % 97) - 0.25 * (double)(i % 7);
+    fHE::context::poly_t enc_poly(L);
+    encoder->encode(&enc_poly, vals, 1099511627776.0);
+    std::vector<double> back;
+    encoder->decode(&back, enc_poly, 1099511627776.0);
+    double enc_err = 0;
+    for (size_t i = 0; i < nr_slots; ++i) enc_err = std::max(enc_err, std::fabs(back[i] - vals[i]));
+    std::printf("encode/decode max error: %.3e\n", enc_err);
+    if (!(enc_err < 1e-6)) { std::fprintf(stderr, "encoder round trip too inaccurate\n"); return 12; }
+    fHE::Cipher nn_in(in_a);
+    nn_in.bx.backward(); nn_in.ax.backward();
+    fHE::Cipher nn(nn_in);
+    if (!evaluator.rotate_slots_non_ntt(&nn, rkey)) { std::fprintf(stderr, "rotate_slots_non_ntt failed\n"); return 13; }
+    fHE::Cipher nn5(nn_in);
+    if (!evaluator.rotate_slots_non_ntt(&nn5, -5, rset)) { std::fprintf(stderr, "rotate_slots_non_ntt(offset) failed\n"); return 14; }
+    const size_t rep_pos = 5;
+    fHE::Cipher rep(in_a);
+    if (!evaluator.replicate(&rep, rep_pos, rset)) { std::fprintf(stderr, "replicate failed\n"); return 15; }
+    fHE::context::poly_t rep_mask(L);
+    { std::vector<double> mask(nr_slots, 0.); mask[rep_pos] = 1.; encoder->encode(&rep_mask, mask, fHE::context::encoder_scale / 8.); }
+
     FILE *f = std::fopen(path, "wb");
     if (!f) { std::perror("fopen"); return 9; }
     uint64_t hdr[4] = {logN, L, K, rkey.galois};
@@ -109,6 +135,11 @@ int main(int argc, char **argv) {
     dump(f, "msg_a", ma); dump(f, "msg_b", mb);
     for (size_t j = 0; j < L; ++j) { dump(f, "xk_beta", *mkey_rot.get_beta_at(j)); dump(f, "xk_alpha", *mkey_rot.get_alpha_at(j)); }
     dump(f, "rotm_bx", rotm.bx); dump(f, "rotm_ax", rotm.ax); dump(f, "dec_rotm", dec_rotm); dump(f, "dec_rot3", dec_rot3);
+    dump(f, "enc_poly", enc_poly);
+    dump(f, "nn_in_bx", nn_in.bx); dump(f, "nn_in_ax", nn_in.ax); dump(f, "nn_bx", nn.bx); dump(f, "nn_ax", nn.ax);
+    dump(f, "nn5_bx", nn5.bx); dump(f, "nn5_ax", nn5.ax);
+    for (size_t i = 0; i + 1 < logN; ++i) { auto k = rset.get((uint16_t)(1u << i)); dump(f, "rs_beta", k->beta); dump(f, "rs_alpha", k->alpha); }
+    dump(f, "rep_mask", rep_mask); dump(f, "rep_bx", rep.bx); dump(f, "rep_ax", rep.ax);
     std::fclose(f);
     std::printf("host_roundtrip OK\n");
     return 0;

@@ -99,6 +99,14 @@ int fhe_hip_mul_relin_rescale(fhe_hip_ctx *ctx, uint64_t *out, const uint64_t *c
  * in place with the RotKey loaded for `galois`; galois == 0 is a no-op (:303-304). */
 int fhe_hip_rotate(fhe_hip_ctx *ctx, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind);
 
+/* Evaluator::rotate_slots_non_ntt(Cipher*, RotKey const&) (src/evaluator.cpp:138-146, 327-339, 520-574): ct = [batch][2][Li][N]
+ * in the POWER basis, in place; apply_galois_non_ntt on both halves, then the hybrid key switch with every limb taken
+ * through NTT -> key product -> INTT and approximated_mod_down applied to the result.  The reference's mod_down adds an
+ * NTT-domain correction to those power-basis limbs (base_converter.cpp:220-239 under evaluator.cpp:563-572); this entry
+ * point reproduces that arithmetic literally, so its output equals the reference's, not a valid rotation.
+ *  */
+int fhe_hip_rotate_non_ntt(fhe_hip_ctx *ctx, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind);
+
 /* MixedRotKey (include/fHE/rot_key.hpp:41-82, src/rot_key.cpp:81-120): beta/alpha = [L][L+1][N] (key i, limb j; limb L
  * lives under the special prime P[L]), NTT basis.   */
 int fhe_hip_load_mixed_rot_key(fhe_hip_ctx *ctx, uint64_t galois, const uint64_t *beta, const uint64_t *alpha, int mem_kind);

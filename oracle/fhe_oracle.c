@@ -468,6 +468,43 @@ int orc_rotate(const orc_ctx *c, u64 *bx, u64 *ax, uint32_t Li, u64 galois, cons
   return 0;
 }
 
+int orc_rotate_non_ntt(const orc_ctx *c, u64 *bx, u64 *ax, uint32_t Li, u64 galois, const u64 *rk_beta, const u64 *rk_alpha) {
+  /* Impl::rotate_slots_inplace_non_ntt evaluator.cpp:327-339 + apply_rotation_key_non_ntt :520-574, literally: the
+   * ciphertext is in the power basis, every limb of d_rotk goes NTT -> key product -> INTT, and approximated_mod_down
+   * (base_converter.cpp:205-242) is then applied as written, i.e. its NTT-domain correction is added to power-basis limbs. */
+  if (!bx || !ax) return -1;
+  if (galois == 0) return 0; /* :331-332 */
+  if (Li > c->L) return -1;  /* "Too many moduli." :530-531 */
+  if (Li <= 1) return -2;    /* mod_up throws, base_converter.cpp:284-285 */
+  const size_t N = c->N; const uint32_t K = c->K, L = c->L;
+  orc_apply_galois_non_ntt(c, bx, Li, galois); /* :333-334 */
+  orc_apply_galois_non_ntt(c, ax, Li, galois);
+  const size_t ext = (size_t)(Li + K) * N;
+  u64 *e0 = (u64 *)malloc(ext * 8), *e1 = (u64 *)malloc(ext * 8);
+  orc_mod_up(c, e0, ax, Li); /* :537 */
+  for (uint32_t cm = 0; cm < Li + K; ++cm) orc_ntt_forward(c, e0 + (size_t)cm * N, cm < Li ? cm : L + (cm - Li)); /* :539-542 */
+  memcpy(e1, e0, ext * 8); /* :543 */
+  for (uint32_t cm = 0; cm < Li + K; ++cm) { /* :549-560 */
+    const uint32_t idx = cm < Li ? cm : L + (cm - Li);
+    const u64 p = c->P[idx];
+    const u64 *b = rk_beta + (size_t)idx * N, *a = rk_alpha + (size_t)idx * N;
+    u64 *o0 = e0 + (size_t)cm * N, *o1 = e1 + (size_t)cm * N;
+    for (size_t d = 0; d < N; ++d) { o0[d] = orc_mulmod(o0[d], b[d], p); o1[d] = orc_mulmod(o1[d], a[d], p); }
+  }
+  for (uint32_t cm = 0; cm < Li + K; ++cm) { /* :563-567 */
+    const uint32_t idx = cm < Li ? cm : L + (cm - Li);
+    orc_ntt_backward(c, e0 + (size_t)cm * N, idx);
+    orc_ntt_backward(c, e1 + (size_t)cm * N, idx);
+  }
+  u64 *cpy = (u64 *)malloc((size_t)Li * N * 8);
+  memcpy(cpy, bx, (size_t)Li * N * 8); /* :569 */
+  orc_mod_down(c, bx, e0, Li); /* :571-572 */
+  orc_mod_down(c, ax, e1, Li);
+  orc_add(c, bx, cpy, Li); /* :573 */
+  free(e0); free(e1); free(cpy);
+  return 0;
+}
+
 int orc_rotate_mixed(const orc_ctx *c, u64 *bx, u64 *ax, uint32_t Li, u64 galois, const u64 *mk_beta, const u64 *mk_alpha) {
   /* rotate_slots_inplace(MixedRotKey) evaluator.cpp:313-325 + apply_rotation_key(MixedRotKey) :403-516 */
   if (!bx || !ax) return -1;

@@ -87,6 +87,9 @@ void orc_multiply_plain(const orc_ctx *c, uint64_t *bx, uint64_t *ax, const uint
 /* rotate_slots(RotKey) (:299-311, 343-399): rk_beta/rk_alpha are [(L+K)][N]; in place on bx, ax */
 int orc_rotate(const orc_ctx *c, uint64_t *bx, uint64_t *ax, uint32_t Li, uint64_t galois,
                const uint64_t *rk_beta, const uint64_t *rk_alpha);
+/* Evaluator::rotate_slots_non_ntt (src/evaluator.cpp:327-339, 520-574), reference arithmetic reproduced literally */
+int orc_rotate_non_ntt(const orc_ctx *c, uint64_t *bx, uint64_t *ax, uint32_t Li, uint64_t galois,
+               const uint64_t *rk_beta, const uint64_t *rk_alpha);
 
 /* MixedRotKey variant: rotate_slots(MixedRotKey) evaluator.cpp:313-325 + apply_rotation_key
  * :403-516; keys beta/alpha = [L][L+1][N] (key i, limb j; limb L is the special prime P[L]); needs K >= 1 */

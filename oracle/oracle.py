@@ -52,6 +52,7 @@ def _load():
         "orc_add": (None, [vp, u64p, u64p, u32]),
         "orc_multiply_plain": (None, [vp, u64p, u64p, u64p, u32]),
         "orc_rotate": (i, [vp, u64p, u64p, u32, u64, u64p, u64p]),
+        "orc_rotate_non_ntt": (i, [vp, u64p, u64p, u32, u64, u64p, u64p]),
         "orc_uniform_poly": (None, [vp, u64p, u32, u32, u64]),
         "orc_keygen_sk": (None, [vp, u64p, u64p, u32, u64]),
         "orc_keygen_pk": (None, [vp, u64p, u64p, u64p, u64]),
@@ -206,6 +207,13 @@ class Oracle:
         rc = lib.orc_rotate(self.h, _p(bx), _p(ax), bx.shape[0], galois, _p(rk_beta), _p(rk_alpha))
         if rc:
             raise ValueError("rotate rc=%d" % rc)
+        return bx, ax
+
+    def rotate_non_ntt(self, bx, ax, galois, rk_beta, rk_alpha):
+        bx, ax = bx.copy(), ax.copy()
+        rc = lib.orc_rotate_non_ntt(self.h, _p(bx), _p(ax), bx.shape[0], galois, _p(rk_beta), _p(rk_alpha))
+        if rc:
+            raise ValueError("rotate_non_ntt rc=%d" % rc)
         return bx, ax
 
     def rotate_mixed(self, bx, ax, galois, mk_beta, mk_alpha):

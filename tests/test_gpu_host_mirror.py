@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as orc
+from oracle.encoder import EncoderOracle
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "fhe_amd", "host", "bin", "host_roundtrip")
@@ -76,3 +77,45 @@ def test_config1_roundtrip_through_cpp_api(tmp_path, logN, L, K):
         want3 = o.apply_galois_non_ntt(d["msg_a"][0].copy(), o.rotation_galois(3))[0]
         d3 = (d["dec_rot3"][0][0].astype(object) - want3.astype(object)) % p0
         assert int(np.minimum(d3, p0 - d3).max()) < 1 << 30
+    # ---- SURVEY 8(f) rank 2 / rank 4 through the C++ API: Encoder, rotate_slots_non_ntt, replicate ----
+    enc = EncoderOracle(logN)
+    slots = N >> 1
+    vals = np.array([1.0 + (i % 97) - 0.25 * (i % 7) for i in range(slots)])
+    want_enc = enc.encode(vals, 2.0 ** 40, o.primes[:L])
+    for l in range(L):  # floating point: coefficients agree to within 2^12 at scale 2^40 (truncation boundary + FFT rounding)
+        pl = int(o.primes[l])
+        df = (d["enc_poly"][0][l].astype(object) - want_enc[l].astype(object)) % pl
+        assert int(np.minimum(df, pl - df).max()) <= 1 << 12
+    back = enc.decode(d["enc_poly"][0], o.primes[:L], 2.0 ** 40)
+    assert np.abs(back.real - vals).max() < 1e-6 and np.abs(back.imag).max() < 1e-6
+    nb, na = o.rotate_non_ntt(d["nn_in_bx"][0], d["nn_in_ax"][0], galois, d["rk_beta"][0], d["rk_alpha"][0])
+    assert np.array_equal(d["nn_in_bx"][0], o.ntt_backward(a_bx.copy(), range(L)))
+    assert np.array_equal(d["nn_bx"][0], nb) and np.array_equal(d["nn_ax"][0], na)
+    rs = list(zip(d["rs_beta"], d["rs_alpha"]))
+    assert len(rs) == logN - 1
+
+    def rot_nn_offset(bx, ax, offset):  # evaluator.cpp:210-232
+        offset = abs(offset) % slots
+        i = 0
+        while offset >> i:
+            if offset & (1 << i):
+                bx, ax = o.rotate_non_ntt(bx, ax, o.rotation_galois(1 << i), rs[i][0], rs[i][1])
+            i += 1
+        return bx, ax
+
+    b5, a5 = rot_nn_offset(d["nn_in_bx"][0], d["nn_in_ax"][0], -5)
+    assert np.array_equal(d["nn5_bx"][0], b5) and np.array_equal(d["nn5_ax"][0], a5)
+    # replicate (evaluator.cpp:234-267) from the mask polynomial the C++ encoder produced
+    want_mask = enc.encode(np.eye(1, slots, 5)[0], 2.0 ** 62 / 8.0, o.primes[:L])
+    for l in range(L):
+        pl = int(o.primes[l])
+        df = (d["rep_mask"][0][l].astype(object) - want_mask[l].astype(object)) % pl
+        assert int(np.minimum(df, pl - df).max()) <= 1 << 12
+    mask_ntt = o.ntt_forward(d["rep_mask"][0].copy(), range(L))
+    rb_, ra_ = o.multiply_plain(a_bx, a_ax, mask_ntt)
+    rb_ = o.ntt_backward(rb_, range(L)); ra_ = o.ntt_backward(ra_, range(L))
+    for i in range(logN - 1):
+        tb, ta = rot_nn_offset(rb_, ra_, 1 << i)
+        rb_, ra_ = o.add(rb_, tb), o.add(ra_, ta)
+    rb_ = o.ntt_forward(rb_, range(L)); ra_ = o.ntt_forward(ra_, range(L))
+    assert np.array_equal(d["rep_bx"][0], rb_) and np.array_equal(d["rep_ax"][0], ra_)

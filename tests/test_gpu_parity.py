@@ -327,6 +327,31 @@ def test_rotate_keyswitch(logN, L, K, Li, sp):
         g.rotate(7, d, Li, batch=B)  # no key loaded for this galois element
 
 
+@pytest.mark.parametrize("logN,L,K,Li,sp", [(10, 4, 4, 4, True), (10, 4, 2, 2, True), (11, 3, 2, 3, False), (12, 9, 3, 9, True)])
+def test_rotate_non_ntt_keyswitch(logN, L, K, Li, sp):
+    """power-basis rotation (evaluator.cpp:327-339, 520-574), the reference's arithmetic taken literally."""
+    o, g = ctx_pair(logN, L, K, sp)
+    sx, ext = o.keygen_sk(seed=190)
+    for off in (1, 2):
+        gal = o.rotation_galois(off)
+        rkb, rka = o.keygen_rot(sx, ext, gal, seed=191 + off)
+        g.load_rot_key(gal, dev(rkb), dev(rka))
+        B = 3
+        ct = np.stack([np.stack([rand_poly(o, range(Li), 300 + 2 * b), rand_poly(o, range(Li), 301 + 2 * b)]) for b in range(B)])
+        want = np.stack([np.stack(o.rotate_non_ntt(ct[b, 0], ct[b, 1], gal, rkb, rka)) for b in range(B)])
+        d = dev(ct)
+        g.rotate_non_ntt(gal, d, Li, batch=B)
+        assert np.array_equal(host(d), want)
+        h = ct.copy()
+        g.rotate_non_ntt(gal, h, Li, batch=B)  # host memory kind
+        assert np.array_equal(h, want)
+    d = dev(ct)
+    g.rotate_non_ntt(0, d, Li, batch=B)  # galois == 0: no-op (evaluator.cpp:331-332)
+    assert np.array_equal(host(d), ct)
+    with pytest.raises(fhe_amd.FheHipError):
+        g.rotate_non_ntt(7, d, Li, batch=B)
+
+
 def test_add_and_multiply_plain():
     o, g = ctx_pair(10, 4, 4)
     a = np.stack([rand_poly(o, range(4), 110 + b) for b in range(2)])

@@ -349,3 +349,36 @@ def test_mixed_rot_key_rotation_decrypts_to_rotated_plaintext():
             else:
                 want[e - o.N] = -m[d]
         assert max(abs(x - y) for x, y in zip(dec, want)) < 1 << 30
+
+
+def test_rotate_non_ntt_is_the_literal_composition_of_the_reference_steps():
+    """evaluator.cpp:327-339, 520-574 step by step from the oracle's primitives; also records that this path, as written in the
+    reference, does not decrypt to the rotated plaintext (its mod_down mixes NTT-domain and power-basis limbs)."""
+    logN, L, K = 6, 3, 2
+    o = orc.Oracle(logN, L, K)
+    sx, ext = o.keygen_sk(seed=41, hwt=8)
+    g = o.rotation_galois(1)
+    rkb, rka = o.keygen_rot(sx, ext, g, seed=43)
+    rng = np.random.default_rng(8)
+    Li = 3
+    bx = np.stack([rng.integers(0, int(o.primes[i]), o.N, dtype=np.uint64) for i in range(Li)])
+    ax = np.stack([rng.integers(0, int(o.primes[i]), o.N, dtype=np.uint64) for i in range(Li)])
+    rb, ra = o.rotate_non_ntt(bx, ax, g, rkb, rka)
+    gb = o.apply_galois_non_ntt(bx.copy(), g)
+    ga = o.apply_galois_non_ntt(ax.copy(), g)
+    idx = [cm if cm < Li else L + cm - Li for cm in range(Li + K)]
+    e0 = o.ntt_forward(o.mod_up(ga), idx)
+    e1 = e0.copy()
+    for cm, m in enumerate(idx):
+        p = int(o.primes[m])
+        e0[cm] = np.array([int(x) * int(k) % p for x, k in zip(e0[cm], rkb[m])], dtype=np.uint64)
+        e1[cm] = np.array([int(x) * int(k) % p for x, k in zip(e1[cm], rka[m])], dtype=np.uint64)
+    e0 = o.ntt_backward(e0, idx)
+    e1 = o.ntt_backward(e1, idx)
+    wb = o.add(o.mod_down(e0), gb)
+    wa = o.mod_down(e1)
+    assert np.array_equal(rb, wb) and np.array_equal(ra, wa)
+    nb, na = o.rotate_non_ntt(bx, ax, 0, rkb, rka)  # galois == 0: no-op (:331-332)
+    assert np.array_equal(nb, bx) and np.array_equal(na, ax)
+    with pytest.raises(ValueError):
+        o.rotate_non_ntt(bx[:1], ax[:1], g, rkb, rka)  # Li <= 1: mod_up throws (base_converter.cpp:284-285)
