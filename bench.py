@@ -27,9 +27,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 WORKLOADS = {
     #        logN  L   K   Li  default batch
-    "c3": (16, 30, 1, 30, 8),
-    "c5": (15, 16, 1, 16, 16),
-    "c4": (16, 30, 30, 30, 4),
+    "c3": (16, 30, 1, 30, 16),
+    "c5": (15, 16, 1, 16, 64),
+    "c4": (16, 30, 30, 30, 16),
     "ntt": (16, 8, 0, 8, 512),
     "c2": (14, 8, 0, 8, 8192),
 }

@@ -85,45 +85,59 @@ struct BconvArgs {
   u64 *out; const u64 *src;
   const u64 *inv_m;   // [nsrc]  Montgomery form w.r.t. the source prime
   const u64 *hat_m;   // [ntgt][hat_stride]  Montgomery form w.r.t. the target prime
+  const u64 *pow2w;   // [M][6]  2^w mod p for the accumulator weights w = 0, 21, 42, 32, 53, 74 (plain residues)
   const PrimeC *primes;
   u32 nsrc, src_first, src_limbs, src_off;
   u32 tgt_first, out_limbs, out_off, hat_stride, ntgt;
   u64 N;
 };
 // One thread = one coefficient x BCONV_TC targets.  Per source limb k the canonical digit t0 = [x_k * inv_k]_{p_k}
-// is computed once and multiplied into BCONV_TC lazy 128-bit accumulators (4 v_mad_u64_u32 + a carry chain per term,
-// no reduction); every 8 terms the accumulators are folded with one Montgomery reduction (hat is in Montgomery
-// form, so the fold yields sum t0*hat mod p directly; 8 terms keep thi < 2^63 so thi - w + p cannot wrap).
-#define BCONV_TC 8
+// is computed once.  Every VALU instruction costs one issue slot on gfx950, so the sum
+// sum_k hat[t][k] * t0_k is accumulated WITHOUT carries: hat (< 2^62, uniform, split by the scalar unit into three
+// 21-bit limbs) times t0 (two 32-bit words) gives six partial products < 2^53, each added into its own 64-bit
+// accumulator by one v_mad_u64_u32 (room for 2^10 terms).  The six accumulators are folded once per target at the end:
+// hat is in Montgomery form, so mont(2^w mod p, acc_w) = acc_w' * 2^w mod p of the plain sum.
+#define BCONV_TC 6
+__device__ constexpr int kBconvWeights[6] = {0, 21, 42, 32, 53, 74};
 template <bool SP>
 __global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
   const u64 d = (u64)blockIdx.x * PW_THREADS + threadIdx.x;
   const u32 tbase = blockIdx.y * BCONV_TC, e = blockIdx.z;
   const u32 ntgt = a.ntgt;
   const u64 *sp = a.src + ((u64)e * a.src_limbs + a.src_off) * a.N + d;
-  u64 hi[BCONV_TC], lo[BCONV_TC], ps[BCONV_TC];
+  u64 acc[BCONV_TC][6];
   u32 tt[BCONV_TC];
 #pragma unroll
-  for (int t = 0; t < BCONV_TC; ++t) { hi[t] = 0; lo[t] = 0; ps[t] = 0; tt[t] = (tbase + t < ntgt) ? tbase + t : ntgt - 1; }
-  for (u32 k0 = 0; k0 < a.nsrc; k0 += 8) {
-    const u32 kend = (k0 + 8 < a.nsrc) ? k0 + 8 : a.nsrc;
-    for (u32 k = k0; k < kend; ++k) {
-      const PrimeC PS = a.primes[a.src_first + k];
-      const u64 t0 = csub(mont_mul<SP>(a.inv_m[k], sp[(u64)k * a.N], PS), PS.p);  // canonical residue mod the source prime
+  for (int t = 0; t < BCONV_TC; ++t) {
+    tt[t] = (tbase + t < ntgt) ? tbase + t : ntgt - 1;
 #pragma unroll
-      for (int t = 0; t < BCONV_TC; ++t) mac128(hi[t], lo[t], a.hat_m[(u64)tt[t] * a.hat_stride + k], t0);
-    }
+    for (int w = 0; w < 6; ++w) acc[t][w] = 0;
+  }
+  for (u32 k = 0; k < a.nsrc; ++k) {
+    const PrimeC PS = a.primes[a.src_first + k];
+    const u64 t0 = csub(mont_mul<SP>(a.inv_m[k], sp[(u64)k * a.N], PS), PS.p);  // canonical residue mod the source prime
+    const u32 b0 = (u32)t0, b1 = (u32)(t0 >> 32);
 #pragma unroll
     for (int t = 0; t < BCONV_TC; ++t) {
-      const PrimeC PT = a.primes[a.tgt_first + tt[t]];
-      const u64 r = csub(csub(mont_reduce<SP>(hi[t], lo[t], PT), PT.twop), PT.p);  // (0,3p) -> [0,p)
-      ps[t] = csub(ps[t] + r, PT.p);
-      hi[t] = 0; lo[t] = 0;
+      const u64 h = a.hat_m[(u64)tt[t] * a.hat_stride + k];  // uniform: scalar load, scalar split
+      const u32 h0 = (u32)h & 0x1FFFFFu, h1 = (u32)(h >> 21) & 0x1FFFFFu, h2 = (u32)(h >> 42);
+      acc[t][0] = mad_wide(h0, b0, acc[t][0]);
+      acc[t][1] = mad_wide(h1, b0, acc[t][1]);
+      acc[t][2] = mad_wide(h2, b0, acc[t][2]);
+      acc[t][3] = mad_wide(h0, b1, acc[t][3]);
+      acc[t][4] = mad_wide(h1, b1, acc[t][4]);
+      acc[t][5] = mad_wide(h2, b1, acc[t][5]);
     }
   }
 #pragma unroll
-  for (int t = 0; t < BCONV_TC; ++t)
-    if (tbase + t < ntgt) a.out[((u64)e * a.out_limbs + a.out_off + tbase + t) * a.N + d] = ps[t];
+  for (int t = 0; t < BCONV_TC; ++t) {
+    const u32 m = a.tgt_first + tt[t];
+    const PrimeC PT = a.primes[m];
+    u64 s = 0;  // lazy in [0, 2p)
+#pragma unroll
+    for (int w = 0; w < 6; ++w) s = csub(s + mont_mul<SP>(a.pow2w[(u64)m * 6 + w], acc[t][w], PT), PT.twop);
+    if (tbase + t < ntgt) a.out[((u64)e * a.out_limbs + a.out_off + tbase + t) * a.N + d] = csub(s, PT.p);
+  }
 }
 
 // tail of approximated_mod_down (src/base_converter.cpp:227-240): out_j = (src_j + conv_j) * P^-1 mod q_j,
