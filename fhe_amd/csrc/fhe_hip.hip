@@ -314,7 +314,7 @@ int dev_mod_down(fhe_hip_ctx *c, u64 *rop, const u64 *op, u32 L0, u32 batch, con
   TRY(dev_conv_to_normal(c, conv, L0, op, L0 + c->K, L0, batch));
   TRY(ntt_simple(c, conv, c->d_iota, L0, batch, (u64)L0 * c->N, false));
   LAUNCH_SP(c, "moddown_final", moddown_final_kernel, pw_grid(c, L0, batch), dim3(PW_THREADS), rop, op, (const u64 *)conv, addend,
-            (const u64 *)c->d_Pinv_qj_m, (const PrimeC *)c->d_primes, L0, L0 + c->K, c->N);
+            (const u64 *)c->d_Pinv_qj_m, (const PrimeC *)c->d_primes, L0, L0 + c->K, c->N, (u64)L0 * c->N, (u64)L0 * c->N);
   return FHE_HIP_OK;
 }
 
@@ -437,15 +437,14 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
     // mod up: special limbs from the power basis; normal limbs of the NTT-domain result are ax_g itself
     // (NTT(INTT(x)) = x for canonical x, so the Li forward NTTs of :363-366 are not recomputed)
     TRY(dev_conv_to_special(c, e0, nl, Li, pw, Li, Li, batch));
-    for (u32 b = 0; b < batch; ++b)
-      HIPCHK(c, hipMemcpyAsync(e0 + (size_t)b * nl * N, g + ((size_t)b * 2 + 1) * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream));
     // forward NTT of the K special limbs
     NttPlan pf{e0 + (size_t)Li * N, e0 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
     TRY(ntt_run(c, pf, false));
   }
   const u32 *rotmap = c->d_rotmap + (size_t)Li * c->M;
   LAUNCH_SP(c, "rot_keymul", rot_keymul_kernel, pw_grid(c, nl, batch), dim3(PW_THREADS), e0, e1, (const u64 *)e0, (const u64 *)it->second.beta_m,
-            (const u64 *)it->second.alpha_m, (const PrimeC *)c->d_primes, rotmap, nl, N);
+            (const u64 *)it->second.alpha_m, (const PrimeC *)c->d_primes, rotmap, nl, N,
+            (const u64 *)(non_ntt ? nullptr : g + (size_t)Li * N), (u64)2 * Li * N, Li);  // NTT path: normal limbs straight from ax_g
   if (non_ntt) {  // every limb back to the power basis (:563-567)
     NttPlan p0{e0, e0, c->d_rotmap + (size_t)Li * c->M, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
     TRY(ntt_run(c, p0, true));
@@ -457,26 +456,16 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
     NttPlan p1{e1 + (size_t)Li * N, e1 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
     TRY(ntt_run(c, p1, true));
   }
-  // mod down both halves into ct; rop[0] += galois(bx) (:394-398).  Output halves are strided [b][2][Li][N]:
-  // run per half with entry stride handled by a temporary contiguous buffer.
-  TRY(ensure_ws(c, 1, (size_t)batch * Li * N * 8 * 2));
-  u64 *o0 = (u64 *)c->ws[1], *o1 = o0 + (size_t)batch * Li * N;
-  // addend for half 0 = bx_g, gathered contiguously
-  TRY(ensure_ws(c, 2, (size_t)batch * Li * N * 8 * 2));
-  u64 *bxg = (u64 *)c->ws[2], *conv = bxg + (size_t)batch * Li * N;
-  for (u32 b = 0; b < batch; ++b)
-    HIPCHK(c, hipMemcpyAsync(bxg + (size_t)b * Li * N, g + (size_t)b * 2 * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream));
+  // mod down both halves straight into ct (strided [b][2][Li][N]); rop[0] += galois(bx) read from g (:394-398)
+  TRY(ensure_ws(c, 2, (size_t)batch * Li * N * 8));
+  u64 *conv = (u64 *)c->ws[2];
   for (int h = 0; h < 2; ++h) {
     const u64 *op = h == 0 ? e0 : e1;
-    u64 *rop = h == 0 ? o0 : o1;
     TRY(dev_conv_to_normal(c, conv, Li, op, nl, Li, batch));
     TRY(ntt_simple(c, conv, c->d_iota, Li, batch, (u64)Li * N, false));
-    LAUNCH_SP(c, "moddown_final", moddown_final_kernel, pw_grid(c, Li, batch), dim3(PW_THREADS), rop, op, (const u64 *)conv,
-              (const u64 *)(h == 0 ? bxg : nullptr), (const u64 *)c->d_Pinv_qj_m, (const PrimeC *)c->d_primes, Li, nl, N);
-  }
-  for (u32 b = 0; b < batch; ++b) {
-    HIPCHK(c, hipMemcpyAsync(ct + (size_t)b * 2 * Li * N, o0 + (size_t)b * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(ct + ((size_t)b * 2 + 1) * Li * N, o1 + (size_t)b * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream));
+    LAUNCH_SP(c, "moddown_final", moddown_final_kernel, pw_grid(c, Li, batch), dim3(PW_THREADS), ct + (size_t)h * Li * N, op, (const u64 *)conv,
+              (const u64 *)(h == 0 ? g : nullptr), (const u64 *)c->d_Pinv_qj_m, (const PrimeC *)c->d_primes, Li, nl, N, (u64)2 * Li * N,
+              (u64)2 * Li * N);
   }
   return FHE_HIP_OK;
 }

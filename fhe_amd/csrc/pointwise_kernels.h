@@ -145,7 +145,7 @@ __global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
 template <bool SP>
 __global__ __launch_bounds__(PW_THREADS) void moddown_final_kernel(u64 *out, const u64 *src, const u64 *conv, const u64 *addend,
                                                                    const u64 *pinv_m, const PrimeC *primes, u32 L0, u32 src_limbs,
-                                                                   u64 N) {
+                                                                   u64 N, u64 out_bstride, u64 add_bstride) {
   const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
   const u32 j = blockIdx.y, e = blockIdx.z;
   const PrimeC P = primes[j];
@@ -154,24 +154,27 @@ __global__ __launch_bounds__(PW_THREADS) void moddown_final_kernel(u64 *out, con
   const ulonglong2 s = ld2(src + ((u64)e * src_limbs + j) * N + d), c = ld2(conv + o);
   u64 r0 = csub(mont_mul<SP>(pi, s.x + c.x, P), P.p), r1 = csub(mont_mul<SP>(pi, s.y + c.y, P), P.p);
   if (addend) {
-    const ulonglong2 ad = ld2(addend + o);
+    const ulonglong2 ad = ld2(addend + (u64)e * add_bstride + (u64)j * N + d);
     r0 = addmod_c(r0, ad.x, P.p); r1 = addmod_c(r1, ad.y, P.p);
   }
-  st2(out + o, r0, r1);
+  st2(out + (u64)e * out_bstride + (u64)j * N + d, r0, r1);
 }
 
 // key multiply of apply_rotation_key (src/evaluator.cpp:373-384): e0 = ext * beta[idx], e1 = ext * alpha[idx],
-// idx = midx[cm] (cm < Li ? cm : L + cm - Li).  ext/e0/e1 = [b][nl][N]; keys [L+K][N] Montgomery form.
+// idx = midx[cm] (cm < Li ? cm : L + cm - Li).  ext/e0/e1 = [b][nl][N]; keys [L+K][N] Montgomery form.  When `norm` is
+// given, limbs cm < nnorm are read from norm = [b](norm_bstride)[nnorm][N] instead of ext (the NTT-domain normal limbs of the
+// extended polynomial are the input itself).
 template <bool SP>
 __global__ __launch_bounds__(PW_THREADS) void rot_keymul_kernel(u64 *e0, u64 *e1, const u64 *ext, const u64 *beta_m,
                                                                 const u64 *alpha_m, const PrimeC *primes, const u32 *midx, u32 nl,
-                                                                u64 N) {
+                                                                u64 N, const u64 *norm, u64 norm_bstride, u32 nnorm) {
   const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
   const u32 cm = blockIdx.y, b = blockIdx.z;
   const u32 m = midx[cm];
   const PrimeC P = primes[m];
   const u64 o = ((u64)b * nl + cm) * N + d;
-  const ulonglong2 x = ld2(ext + o), kb = ld2(beta_m + (u64)m * N + d), ka = ld2(alpha_m + (u64)m * N + d);
+  const u64 *xs = (norm && cm < nnorm) ? norm + (u64)b * norm_bstride + (u64)cm * N + d : ext + o;
+  const ulonglong2 x = ld2(xs), kb = ld2(beta_m + (u64)m * N + d), ka = ld2(alpha_m + (u64)m * N + d);
   st2(e0 + o, csub(mont_mul<SP>(kb.x, x.x, P), P.p), csub(mont_mul<SP>(kb.y, x.y, P), P.p));
   st2(e1 + o, csub(mont_mul<SP>(ka.x, x.x, P), P.p), csub(mont_mul<SP>(ka.y, x.y, P), P.p));
 }
