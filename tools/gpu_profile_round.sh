@@ -12,14 +12,17 @@ for wl in c4 c5 c2; do
   timeout -k 10 300 python -u bench.py --workload $wl --steps 5 --warmup 1 > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err || { tail -20 $OUT/bench_$wl.err; exit 1; }
 done
 cd /tmp && export TMPDIR=/tmp
-for wl in c3 ntt; do
+for wl in c3 ntt c4; do
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline > $OUT/stats_$wl.log 2>&1 || { tail -20 $OUT/stats_$wl.log; exit 1; }
   timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$wl -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > $OUT/fetch_$wl.log 2>&1 || { tail -5 $OUT/fetch_$wl.log; exit 1; }
   timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$wl -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > $OUT/write_$wl.log 2>&1 || { tail -5 $OUT/write_$wl.log; exit 1; }
 done
-for wl in c3 ntt; do
+for wl in c3 ntt c4; do
   mkdir -p $OUT/pmc_$wl && cp -r $OUT/fetch_$wl $OUT/write_$wl $OUT/pmc_$wl/ 2>/dev/null
   python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT/pmc_$wl > $OUT/pmc_summary_$wl.txt
   rm -rf $OUT/pmc_$wl
 done
+python3 $GRAFT_REPO_ROOT/tools/make_traffic_json.py $OUT/pmc_summary_c3.txt c3 "c3, default batch per launch, N=2^16 Li=30" $OUT/traffic_c3.json relin_rows_mac_kernel
+python3 $GRAFT_REPO_ROOT/tools/make_traffic_json.py $OUT/pmc_summary_ntt.txt ntt "ntt, 512 limbs/launch, N=2^16" $OUT/traffic_ntt.json "ntt_cols_kernel<true, false" "ntt_rows_kernel<true, false"
+python3 $GRAFT_REPO_ROOT/tools/make_traffic_json.py $OUT/pmc_summary_c4.txt c4 "c4, default batch per launch, N=2^16 Li=K=30 (one base-conversion launch)" $OUT/traffic_c4.json bconv_kernel
 cat $OUT/pmc_summary_c3.txt | head -40
