@@ -632,9 +632,9 @@ int fhe_hip_sync(fhe_hip_ctx *c) { TRY(check_ctx(c)); HIPCHK(c, hipStreamSynchro
 
 static int ntt_api(fhe_hip_ctx *c, uint64_t *limbs, const uint32_t *moduli_idx, size_t n_limbs, int mem_kind, bool inverse) {
   TRY(check_ctx(c));
+  if (n_limbs == 0) return FHE_HIP_OK;  // an empty batch is a no-op, whatever the pointers
   if (!limbs || !moduli_idx) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   for (size_t i = 0; i < n_limbs; ++i) if (moduli_idx[i] >= c->M) FAIL(c, FHE_HIP_ERR_RANGE, "moduli_idx out of range");
-  if (n_limbs == 0) return FHE_HIP_OK;
   Staged st(c, mem_kind);
   u64 *d = nullptr;
   TRY(st.out(limbs, n_limbs * c->N * 8, &d, true));
