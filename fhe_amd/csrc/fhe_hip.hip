@@ -174,6 +174,11 @@ struct NttPlan {
   u64 src_bstride, dst_bstride;
   u32 skip_diag = 0;
   bool cols_only = false;  // forward only: stop after the column pass (the row pass is fused elsewhere)
+  // forward only: epilogue fused into the row pass (NttArgs::epi); dst is then only the column-pass scratch
+  u32 epi = 0;
+  const u64 *epi_src = nullptr, *epi_c = nullptr, *epi_add = nullptr;
+  u64 *epi_out = nullptr;
+  u64 epi_src_bstride = 0, epi_add_bstride = 0, epi_out_bstride = 0;
 };
 
 template <bool SP, bool INV>
@@ -197,6 +202,10 @@ template <bool SP, bool INV>
 int launch_rows(fhe_hip_ctx *c, const NttArgs &a, u32 nl, u32 batch) {
   const u32 R = 1u << c->logR, rows = R < 16 ? R : 16;
   dim3 grid(R / rows, nl, batch), block(16 * rows);
+  if constexpr (!INV) {
+    if (a.epi == 1) { LAUNCH(c, "ntt_fwd_rows_rescale", (ntt_rows_kernel<SP, false, 1>), grid, block, a); return FHE_HIP_OK; }
+    if (a.epi == 2) { LAUNCH(c, "ntt_fwd_rows_moddown", (ntt_rows_kernel<SP, false, 2>), grid, block, a); return FHE_HIP_OK; }
+  }
   LAUNCH(c, INV ? "ntt_inv_rows" : "ntt_fwd_rows", (ntt_rows_kernel<SP, INV>), grid, block, a);
   return FHE_HIP_OK;
 }
@@ -209,6 +218,8 @@ int ntt_run_sp(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
   a.primes = c->d_primes; a.midx = p.midx; a.mdiv = p.mdiv; a.mper = p.mper;
   a.logN = c->logN; a.logR = c->logR; a.l0 = 0; a.skip_diag = p.skip_diag;
   a.dst = p.dst; a.dst_bstride = p.dst_bstride;
+  a.epi = inverse ? 0 : p.epi; a.epi_src = p.epi_src; a.epi_c = p.epi_c; a.epi_add = p.epi_add; a.epi_out = p.epi_out;
+  a.epi_src_bstride = p.epi_src_bstride; a.epi_add_bstride = p.epi_add_bstride; a.epi_out_bstride = p.epi_out_bstride;
   // first pass reads the (possibly broadcast) source, second pass runs in place on dst
   NttArgs first = a, second = a;
   first.src = p.src; first.src_bstride = p.src_bstride; first.smod = p.smod;
@@ -312,9 +323,11 @@ int dev_mod_down(fhe_hip_ctx *c, u64 *rop, const u64 *op, u32 L0, u32 batch, con
   TRY(ensure_ws(c, ws_slot, bytes));
   u64 *conv = (u64 *)c->ws[ws_slot];
   TRY(dev_conv_to_normal(c, conv, L0, op, L0 + c->K, L0, batch));
-  TRY(ntt_simple(c, conv, c->d_iota, L0, batch, (u64)L0 * c->N, false));
-  LAUNCH_SP(c, "moddown_final", moddown_final_kernel, pw_grid(c, L0, batch), dim3(PW_THREADS), rop, op, (const u64 *)conv, addend,
-            (const u64 *)c->d_Pinv_qj_m, (const PrimeC *)c->d_primes, L0, L0 + c->K, c->N, (u64)L0 * c->N, (u64)L0 * c->N);
+  // forward NTT of the conversion with the tail (op_j + conv_j) * P^-1 [+ addend] fused into its row pass (:227-240)
+  NttPlan p{conv, conv, c->d_iota, 1, L0, L0, L0, batch, (u64)L0 * c->N, (u64)L0 * c->N};
+  p.epi = 2; p.epi_src = op; p.epi_src_bstride = (u64)(L0 + c->K) * c->N; p.epi_c = c->d_Pinv_qj_m;
+  p.epi_add = addend; p.epi_add_bstride = (u64)L0 * c->N; p.epi_out = rop; p.epi_out_bstride = (u64)L0 * c->N;
+  TRY(ntt_run(c, p, false));
   return FHE_HIP_OK;
 }
 
@@ -324,10 +337,11 @@ int dev_rescale(fhe_hip_ctx *c, u64 *rop, const u64 *op, u32 n, u32 entries, int
   TRY(ensure_ws(c, ws_slot, (size_t)entries * (n - 1) * N * 8));
   u64 *tail = (u64 *)c->ws[ws_slot];
   // tail[e][j] = NTT_j(op[e][n-1]) for j < n-1 (src limb broadcast: smod = 1 from the last limb)
+  // the row pass ends with rop_j = (op_j + q_j - tail_j) * q_last^-1 (base_converter.cpp:264-271): tail never leaves the chip
   NttPlan p{op + (size_t)(n - 1) * N, tail, c->d_iota, 1, n - 1, 1, n - 1, entries, (u64)n * N, (u64)(n - 1) * N};
+  p.epi = 1; p.epi_src = op; p.epi_src_bstride = (u64)n * N; p.epi_c = c->d_qinv_m + (size_t)(n - 1) * c->M;
+  p.epi_out = rop; p.epi_out_bstride = (u64)(n - 1) * N;
   TRY(ntt_run(c, p, false));
-  LAUNCH_SP(c, "rescale", rescale_kernel, pw_grid(c, n - 1, entries), dim3(PW_THREADS), rop, op, (const u64 *)tail,
-            (const u64 *)(c->d_qinv_m + (size_t)(n - 1) * c->M), (const PrimeC *)c->d_primes, n, N);
   return FHE_HIP_OK;
 }
 
@@ -462,10 +476,11 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
   for (int h = 0; h < 2; ++h) {
     const u64 *op = h == 0 ? e0 : e1;
     TRY(dev_conv_to_normal(c, conv, Li, op, nl, Li, batch));
-    TRY(ntt_simple(c, conv, c->d_iota, Li, batch, (u64)Li * N, false));
-    LAUNCH_SP(c, "moddown_final", moddown_final_kernel, pw_grid(c, Li, batch), dim3(PW_THREADS), ct + (size_t)h * Li * N, op, (const u64 *)conv,
-              (const u64 *)(h == 0 ? g : nullptr), (const u64 *)c->d_Pinv_qj_m, (const PrimeC *)c->d_primes, Li, nl, N, (u64)2 * Li * N,
-              (u64)2 * Li * N);
+    NttPlan p{conv, conv, c->d_iota, 1, Li, Li, Li, batch, (u64)Li * N, (u64)Li * N};
+    p.epi = 2; p.epi_src = op; p.epi_src_bstride = (u64)nl * N; p.epi_c = c->d_Pinv_qj_m;
+    p.epi_add = h == 0 ? g : nullptr; p.epi_add_bstride = (u64)2 * Li * N;
+    p.epi_out = ct + (size_t)h * Li * N; p.epi_out_bstride = (u64)2 * Li * N;
+    TRY(ntt_run(c, p, false));
   }
   return FHE_HIP_OK;
 }

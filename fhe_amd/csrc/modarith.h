@@ -163,24 +163,6 @@ __device__ __forceinline__ u64 mont_mul(u64 a, u64 b, const PrimeC &P) {
   }
 }
 
-// previous candidate (carry words through compiler-visible add/addc chains), kept for tools/ubench/bfly.hip
-__device__ __forceinline__ u64 mont_diff_v1(u64 a, u64 b, const PrimeC &P) {
-  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-  const u32 p1 = P.p1;
-  const u64 t0 = mad_op0(a0, b0);
-  u32 c, c1, c2, w1, w2;
-  const u32 hlo = __builtin_addc((u32)(t0 >> 32), p1 + 1u, 0u, &c);
-  const u64 t1 = mad_op(a1, b0, pair64(hlo, c));
-  const u64 m = mad_op(~(u32)t0, p1, t1);
-  const u64 t2 = mad_op0(a0, b1);
-  const u32 V0 = __builtin_addc((u32)t2, (u32)m, 0u, &c1);
-  const u32 V1 = __builtin_addc((u32)(t2 >> 32), (u32)(m >> 32), c1, &c2);
-  const u64 n = mad_op0(V0, p1);
-  const u32 elo = __builtin_subc(V1, (u32)n, 0u, &w1);
-  const u32 ehi = __builtin_subc(c2, (u32)(n >> 32), w1, &w2);
-  return mad_op(a1, b1, pair64(elo, ehi));
-}
-
 template <bool SP>
 __device__ __forceinline__ void ct_bfly_ref(u64 &X, u64 &Y, u64 W, const PrimeC &P) {
   const u64 D = mont_diff_ref<SP>(W, Y, P);

@@ -26,6 +26,14 @@ struct NttArgs {
   u32 l0;               // limb offset: limb id = blockIdx.y + l0
   u32 skip_diag;        // if nonzero (= Li): skip limbs with (l / Li) == (l % Li)  (relinearisation, j == i)
   u64 src_bstride, dst_bstride;  // elements between batch entries
+  // optional epilogue fused into the forward row pass (the NTT result t never reaches HBM):
+  //   epi == 1: out = (src + 2p - t) * c mod p          BaseConverter::rescale inner loop (src/base_converter.cpp:264-271)
+  //   epi == 2: out = (src + t) * c [+ add] mod p       tail of approximated_mod_down (:227-240) [+ evaluator.cpp:398]
+  // src/add/out = [b](bstride)[limb][N] addressed by the same (b, limb) as the NTT; c[modulus index] in Montgomery form.
+  u32 epi;
+  const u64 *epi_src, *epi_c, *epi_add;
+  u64 *epi_out;
+  u64 epi_src_bstride, epi_add_bstride, epi_out_bstride;
 };
 
 // LDS hand-off inside one wave (a 256-element row is owned by 16 consecutive lanes of one wave)
@@ -85,7 +93,7 @@ __device__ __forceinline__ void inv_phase(u64 (&e)[1 << LK], const u64 *__restri
 // ---------------------------------------------------------------------------------------------
 constexpr int ROW_LDS = 16 * 18;
 
-template <bool SP, bool INVERSE>
+template <bool SP, bool INVERSE, int EPI = 0>
 __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
 #if defined(NTT_ABL) && NTT_ABL == 4
   __shared__ __attribute__((aligned(16))) u64 lds[32 * ROW_LDS];  // occupancy experiment: 2 workgroups per CU
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
     }
     fwd_phase<SP, 4>(e, tw, (baseA << 4) + t, P);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) e[k] = canon4(e[k], P);
+    for (int k = 0; k < 16; ++k) e[k] = (EPI == 0) ? canon4(e[k], P) : csub(e[k], P.twop);  // epilogue takes t in [0,2p)
     wave_lds_sync();
 #pragma unroll
     for (int k = 0; k < 16; k += 2) *reinterpret_cast<ulonglong2 *>(&L[t * 18 + k]) = make_ulonglong2(e[k], e[k + 1]);
@@ -137,7 +145,26 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
 #if defined(NTT_ABL) && NTT_ABL == 2
       if (v.x == 0x123456789ull) d[32 * i + 2 * t] = v.y;
 #else
-      *reinterpret_cast<ulonglong2 *>(&d[32 * i + 2 * t]) = v;
+      if constexpr (EPI == 0) {
+        *reinterpret_cast<ulonglong2 *>(&d[32 * i + 2 * t]) = v;
+      } else {
+        const u64 off = (u64)l * N + (u64)row * 256 + 32 * i + 2 * t;
+        const ulonglong2 h = *reinterpret_cast<const ulonglong2 *>(&a.epi_src[(u64)b * a.epi_src_bstride + off]);
+        const u64 cm = a.epi_c[m];
+        u64 r0, r1;
+        if constexpr (EPI == 1) {
+          r0 = csub(mont_mul<SP>(cm, h.x + P.twop - v.x, P), P.p);
+          r1 = csub(mont_mul<SP>(cm, h.y + P.twop - v.y, P), P.p);
+        } else {
+          r0 = csub(mont_mul<SP>(cm, h.x + v.x, P), P.p);
+          r1 = csub(mont_mul<SP>(cm, h.y + v.y, P), P.p);
+          if (a.epi_add) {
+            const ulonglong2 ad = *reinterpret_cast<const ulonglong2 *>(&a.epi_add[(u64)b * a.epi_add_bstride + off]);
+            r0 = csub(r0 + ad.x, P.p); r1 = csub(r1 + ad.y, P.p);
+          }
+        }
+        *reinterpret_cast<ulonglong2 *>(&a.epi_out[(u64)b * a.epi_out_bstride + off]) = make_ulonglong2(r0, r1);
+      }
 #endif
     }
   } else {

@@ -38,31 +38,6 @@ __global__ __launch_bounds__(PW_THREADS) void cross_mult_kernel(u64 *out3, const
   st2(out3 + o + 2 * half, r2[0], r2[1]);
 }
 
-// key-MAC of Mul::reLinearize (src/evaluator.cpp:666-691): out[h][i] = (sum_j key_h[j][i] * t[i][j] + ct[h][i]) mod q_i
-// t = [b][Li(i)][Li(j)][N]; keys in Montgomery form [L][L][N]; ct3 = [b][3][Li][N]; out = [b][2][Li][N]
-template <bool SP>
-__global__ __launch_bounds__(PW_THREADS) void relin_mac_kernel(u64 *out, const u64 *t, const u64 *ct3, const u64 *beta_m,
-                                                               const u64 *alpha_m, const PrimeC *primes, u32 Li, u32 L, u64 N) {
-  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
-  const u32 i = blockIdx.y, b = blockIdx.z;
-  const PrimeC P = primes[i];
-  const u64 *tp = t + (((u64)b * Li + i) * Li) * N + d;
-  u64 acc0[2] = {0, 0}, acc1[2] = {0, 0};
-  for (u32 j = 0; j < Li; ++j) {
-    const ulonglong2 x = ld2(tp + (u64)j * N);
-    const ulonglong2 kb = ld2(beta_m + ((u64)j * L + i) * N + d), ka = ld2(alpha_m + ((u64)j * L + i) * N + d);
-    acc0[0] = csub(acc0[0] + mont_mul<SP>(kb.x, x.x, P), P.twop);
-    acc0[1] = csub(acc0[1] + mont_mul<SP>(kb.y, x.y, P), P.twop);
-    acc1[0] = csub(acc1[0] + mont_mul<SP>(ka.x, x.x, P), P.twop);
-    acc1[1] = csub(acc1[1] + mont_mul<SP>(ka.y, x.y, P), P.twop);
-  }
-  const u64 ci = ((u64)b * 3 * Li + i) * N + d, half = (u64)Li * N;
-  const ulonglong2 d0 = ld2(ct3 + ci), d1 = ld2(ct3 + ci + half);
-  const u64 o = ((u64)b * 2 * Li + i) * N + d;
-  st2(out + o, addmod_c(csub(acc0[0], P.p), d0.x, P.p), addmod_c(csub(acc0[1], P.p), d0.y, P.p));
-  st2(out + o + half, addmod_c(csub(acc1[0], P.p), d1.x, P.p), addmod_c(csub(acc1[1], P.p), d1.y, P.p));
-}
-
 // BaseConverter::rescale inner loop (src/base_converter.cpp:264-271): out_j = (head_j + q_j - tail_j) * q_last^-1 mod q_j
 // head = [e][n][N] (limbs j < n-1 used), tail = [e][n-1][N], out = [e][n-1][N]; qinv_m = row (n-1) of the
 // (P[a]^-1 mod P[j]) table in Montgomery form.
@@ -138,26 +113,6 @@ __global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
     for (int w = 0; w < 6; ++w) s = csub(s + mont_mul<SP>(a.pow2w[(u64)m * 6 + w], acc[t][w], PT), PT.twop);
     if (tbase + t < ntgt) a.out[((u64)e * a.out_limbs + a.out_off + tbase + t) * a.N + d] = csub(s, PT.p);
   }
-}
-
-// tail of approximated_mod_down (src/base_converter.cpp:227-240): out_j = (src_j + conv_j) * P^-1 mod q_j,
-// optionally followed by "+ addend_j" (evaluator.cpp:398).  src = [e][src_limbs][N], conv/out/addend = [e][L0][N].
-template <bool SP>
-__global__ __launch_bounds__(PW_THREADS) void moddown_final_kernel(u64 *out, const u64 *src, const u64 *conv, const u64 *addend,
-                                                                   const u64 *pinv_m, const PrimeC *primes, u32 L0, u32 src_limbs,
-                                                                   u64 N, u64 out_bstride, u64 add_bstride) {
-  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
-  const u32 j = blockIdx.y, e = blockIdx.z;
-  const PrimeC P = primes[j];
-  const u64 pi = pinv_m[j];
-  const u64 o = ((u64)e * L0 + j) * N + d;
-  const ulonglong2 s = ld2(src + ((u64)e * src_limbs + j) * N + d), c = ld2(conv + o);
-  u64 r0 = csub(mont_mul<SP>(pi, s.x + c.x, P), P.p), r1 = csub(mont_mul<SP>(pi, s.y + c.y, P), P.p);
-  if (addend) {
-    const ulonglong2 ad = ld2(addend + (u64)e * add_bstride + (u64)j * N + d);
-    r0 = addmod_c(r0, ad.x, P.p); r1 = addmod_c(r1, ad.y, P.p);
-  }
-  st2(out + (u64)e * out_bstride + (u64)j * N + d, r0, r1);
 }
 
 // key multiply of apply_rotation_key (src/evaluator.cpp:373-384): e0 = ext * beta[idx], e1 = ext * alpha[idx],
