@@ -179,6 +179,8 @@ struct NttPlan {
   const u64 *epi_src = nullptr, *epi_c = nullptr, *epi_add = nullptr;
   u64 *epi_out = nullptr;
   u64 epi_src_bstride = 0, epi_add_bstride = 0, epi_out_bstride = 0;
+  const u32 *perm = nullptr;          // inverse only: gather the source through a galois index table
+  const u32 *epi_add_perm = nullptr;  // gather the epilogue addend through a galois index table
 };
 
 template <bool SP, bool INV>
@@ -220,9 +222,11 @@ int ntt_run_sp(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
   a.dst = p.dst; a.dst_bstride = p.dst_bstride;
   a.epi = inverse ? 0 : p.epi; a.epi_src = p.epi_src; a.epi_c = p.epi_c; a.epi_add = p.epi_add; a.epi_out = p.epi_out;
   a.epi_src_bstride = p.epi_src_bstride; a.epi_add_bstride = p.epi_add_bstride; a.epi_out_bstride = p.epi_out_bstride;
+  a.perm = nullptr; a.epi_add_perm = p.epi_add_perm;
   // first pass reads the (possibly broadcast) source, second pass runs in place on dst
   NttArgs first = a, second = a;
   first.src = p.src; first.src_bstride = p.src_bstride; first.smod = p.smod;
+  if (inverse) first.perm = p.perm;
   second.src = p.dst; second.src_bstride = p.dst_bstride; second.smod = p.nl;
   if (!inverse) {
     TRY((launch_cols<SP, false>(c, first, p.nl, p.batch)));
@@ -427,6 +431,10 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
   TRY(ensure_ws(c, 5, extb));      // e1
   TRY(ensure_ws(c, 0, (size_t)batch * Li * N * 8));  // power-basis copy of ax_g
   u64 *g = (u64 *)c->ws[3], *e0 = (u64 *)c->ws[4], *e1 = (u64 *)c->ws[5], *pw = (u64 *)c->ws[0];
+  // NTT path with a real permutation: only galois(bx) is materialised (it is the in-place addend of half 0); galois(ax) is
+  // applied inside the loads of its two readers (inverse row pass, key product).
+  const bool fused = !identity && !non_ntt;
+  const u64 g_bstride = fused ? (u64)Li * N : (u64)2 * Li * N;
   if (identity) {
     HIPCHK(c, hipMemcpyAsync(g, ct, ctb, hipMemcpyDeviceToDevice, c->stream));
   } else if (non_ntt) {
@@ -434,9 +442,10 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
            (const PrimeC *)c->d_primes, c->logN, galois, Li);
   } else {
     TRY(get_galois_perm(c, galois, &perm));
-    LAUNCH(c, "galois_gather", galois_gather_kernel, dim3((unsigned)(N / PW_THREADS), 2 * Li, batch), dim3(PW_THREADS), g, (const u64 *)ct,
-           (const u32 *)perm, N);
+    LAUNCH(c, "galois_gather", galois_gather_kernel, dim3((unsigned)(N / PW_THREADS), Li, batch), dim3(PW_THREADS), g, (const u64 *)ct,
+           (const u32 *)perm, N, (u64)2 * Li * N, g_bstride);
   }
+  const u64 *axg = fused ? ct + (size_t)Li * N : g + (size_t)Li * N;  // galois(ax), through perm when fused
   if (non_ntt) {
     // ax_g is already in the power basis (:537): mod up, then forward NTT of all Li+K limbs (:539-542)
     TRY(dev_conv_to_special(c, e0, nl, Li, g + (size_t)Li * N, 2 * Li, Li, batch));
@@ -446,7 +455,8 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
     TRY(ntt_run(c, pf, false));
   } else {
     // power basis of ax_g (d[1]->backward(), :360)
-    NttPlan pi{g + (size_t)Li * N, pw, c->d_iota, 1, Li, Li, Li, batch, (u64)2 * Li * N, (u64)Li * N};
+    NttPlan pi{axg, pw, c->d_iota, 1, Li, Li, Li, batch, (u64)2 * Li * N, (u64)Li * N};
+    pi.perm = fused ? perm : nullptr;
     TRY(ntt_run(c, pi, true));
     // mod up: special limbs from the power basis; normal limbs of the NTT-domain result are ax_g itself
     // (NTT(INTT(x)) = x for canonical x, so the Li forward NTTs of :363-366 are not recomputed)
@@ -458,7 +468,7 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
   const u32 *rotmap = c->d_rotmap + (size_t)Li * c->M;
   LAUNCH_SP(c, "rot_keymul", rot_keymul_kernel, pw_grid(c, nl, batch), dim3(PW_THREADS), e0, e1, (const u64 *)e0, (const u64 *)it->second.beta_m,
             (const u64 *)it->second.alpha_m, (const PrimeC *)c->d_primes, rotmap, nl, N,
-            (const u64 *)(non_ntt ? nullptr : g + (size_t)Li * N), (u64)2 * Li * N, Li);  // NTT path: normal limbs straight from ax_g
+            (const u64 *)(non_ntt ? nullptr : axg), (u64)2 * Li * N, Li, (const u32 *)(fused ? perm : nullptr));  // NTT path: normal limbs straight from ax_g
   if (non_ntt) {  // every limb back to the power basis (:563-567)
     NttPlan p0{e0, e0, c->d_rotmap + (size_t)Li * c->M, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
     TRY(ntt_run(c, p0, true));
@@ -478,7 +488,7 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
     TRY(dev_conv_to_normal(c, conv, Li, op, nl, Li, batch));
     NttPlan p{conv, conv, c->d_iota, 1, Li, Li, Li, batch, (u64)Li * N, (u64)Li * N};
     p.epi = 2; p.epi_src = op; p.epi_src_bstride = (u64)nl * N; p.epi_c = c->d_Pinv_qj_m;
-    p.epi_add = h == 0 ? g : nullptr; p.epi_add_bstride = (u64)2 * Li * N;
+    p.epi_add = h == 0 ? g : nullptr; p.epi_add_bstride = g_bstride;
     p.epi_out = ct + (size_t)h * Li * N; p.epi_out_bstride = (u64)2 * Li * N;
     TRY(ntt_run(c, p, false));
   }
@@ -502,7 +512,7 @@ int dev_rotate_mixed(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch) {
     u32 *perm = nullptr;
     TRY(get_galois_perm(c, galois, &perm));
     LAUNCH(c, "galois_gather", galois_gather_kernel, dim3((unsigned)(N / PW_THREADS), 2 * Li, batch), dim3(PW_THREADS), g, (const u64 *)ct,
-           (const u32 *)perm, N);
+           (const u32 *)perm, N, (u64)2 * Li * N, (u64)2 * Li * N);
   }
   // [ct_1]_qi -> power basis (:425-427)
   NttPlan pi{g + (size_t)Li * N, pw, c->d_iota, 1, Li, Li, Li, batch, (u64)2 * Li * N, (u64)Li * N};
@@ -683,7 +693,8 @@ static int galois_api(fhe_hip_ctx *c, uint64_t *polys, uint32_t nlimbs, uint64_t
   if (ntt_domain) {
     u32 *perm = nullptr;
     TRY(get_galois_perm(c, galois, &perm));
-    LAUNCH(c, "galois_gather", galois_gather_kernel, grid, dim3(PW_THREADS), d, (const u64 *)tmp, (const u32 *)perm, c->N);
+    LAUNCH(c, "galois_gather", galois_gather_kernel, grid, dim3(PW_THREADS), d, (const u64 *)tmp, (const u32 *)perm, c->N, (u64)nlimbs * c->N,
+           (u64)nlimbs * c->N);
   } else {
     LAUNCH(c, "galois_coeff", galois_coeff_kernel, grid, dim3(PW_THREADS), d, (const u64 *)tmp, (const PrimeC *)c->d_primes, c->logN, galois, nlimbs);
   }

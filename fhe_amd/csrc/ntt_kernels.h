@@ -30,6 +30,8 @@ struct NttArgs {
   //   epi == 1: out = (src + 2p - t) * c mod p          BaseConverter::rescale inner loop (src/base_converter.cpp:264-271)
   //   epi == 2: out = (src + t) * c [+ add] mod p       tail of approximated_mod_down (:227-240) [+ evaluator.cpp:398]
   // src/add/out = [b](bstride)[limb][N] addressed by the same (b, limb) as the NTT; c[modulus index] in Montgomery form.
+  const u32 *perm;   // inverse row pass only: element d of a limb is read from src[perm[d]] (fHE::apply_galois fused into the load)
+  const u32 *epi_add_perm;  // same for the epilogue addend
   u32 epi;
   const u64 *epi_src, *epi_c, *epi_add;
   u64 *epi_out;
@@ -159,7 +161,14 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
           r0 = csub(mont_mul<SP>(cm, h.x + v.x, P), P.p);
           r1 = csub(mont_mul<SP>(cm, h.y + v.y, P), P.p);
           if (a.epi_add) {
-            const ulonglong2 ad = *reinterpret_cast<const ulonglong2 *>(&a.epi_add[(u64)b * a.epi_add_bstride + off]);
+            ulonglong2 ad;
+            if (a.epi_add_perm) {
+              const u64 *al = a.epi_add + (u64)b * a.epi_add_bstride + (u64)l * N;
+              const uint2 pi = *reinterpret_cast<const uint2 *>(&a.epi_add_perm[row * 256 + 32 * i + 2 * t]);
+              ad = make_ulonglong2(al[pi.x], al[pi.y]);
+            } else {
+              ad = *reinterpret_cast<const ulonglong2 *>(&a.epi_add[(u64)b * a.epi_add_bstride + off]);
+            }
             r0 = csub(r0 + ad.x, P.p); r1 = csub(r1 + ad.y, P.p);
           }
         }
@@ -171,7 +180,14 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
     // inverse: spans 1..8 first (thread holds {16t + k}), then spans 16..128 ({t + 16k}); output lazy [0,2p)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&s[32 * i + 2 * t]);
+      ulonglong2 v;
+      if (a.perm) {
+        const u64 *sl = s - (u64)row * 256;  // limb base
+        const uint2 pi = *reinterpret_cast<const uint2 *>(&a.perm[row * 256 + 32 * i + 2 * t]);
+        v = make_ulonglong2(sl[pi.x], sl[pi.y]);
+      } else {
+        v = *reinterpret_cast<const ulonglong2 *>(&s[32 * i + 2 * t]);
+      }
       *reinterpret_cast<ulonglong2 *>(&L[(2 * i + (t >> 3)) * 18 + ((2 * t) & 15)]) = v;
     }
     wave_lds_sync();

@@ -118,27 +118,35 @@ __global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
 // key multiply of apply_rotation_key (src/evaluator.cpp:373-384): e0 = ext * beta[idx], e1 = ext * alpha[idx],
 // idx = midx[cm] (cm < Li ? cm : L + cm - Li).  ext/e0/e1 = [b][nl][N]; keys [L+K][N] Montgomery form.  When `norm` is
 // given, limbs cm < nnorm are read from norm = [b](norm_bstride)[nnorm][N] instead of ext (the NTT-domain normal limbs of the
-// extended polynomial are the input itself).
+// extended polynomial are the input itself); with norm_perm element d is norm[..][norm_perm[d]] (apply_galois fused into the read).
 template <bool SP>
 __global__ __launch_bounds__(PW_THREADS) void rot_keymul_kernel(u64 *e0, u64 *e1, const u64 *ext, const u64 *beta_m,
                                                                 const u64 *alpha_m, const PrimeC *primes, const u32 *midx, u32 nl,
-                                                                u64 N, const u64 *norm, u64 norm_bstride, u32 nnorm) {
+                                                                u64 N, const u64 *norm, u64 norm_bstride, u32 nnorm, const u32 *norm_perm) {
   const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
   const u32 cm = blockIdx.y, b = blockIdx.z;
   const u32 m = midx[cm];
   const PrimeC P = primes[m];
   const u64 o = ((u64)b * nl + cm) * N + d;
-  const u64 *xs = (norm && cm < nnorm) ? norm + (u64)b * norm_bstride + (u64)cm * N + d : ext + o;
-  const ulonglong2 x = ld2(xs), kb = ld2(beta_m + (u64)m * N + d), ka = ld2(alpha_m + (u64)m * N + d);
+  ulonglong2 x;
+  if (norm && cm < nnorm) {
+    const u64 *xl = norm + (u64)b * norm_bstride + (u64)cm * N;
+    if (norm_perm) { const uint2 pi = *reinterpret_cast<const uint2 *>(&norm_perm[d]); x = make_ulonglong2(xl[pi.x], xl[pi.y]); }
+    else x = ld2(xl + d);
+  } else {
+    x = ld2(ext + o);
+  }
+  const ulonglong2 kb = ld2(beta_m + (u64)m * N + d), ka = ld2(alpha_m + (u64)m * N + d);
   st2(e0 + o, csub(mont_mul<SP>(kb.x, x.x, P), P.p), csub(mont_mul<SP>(kb.y, x.y, P), P.p));
   st2(e1 + o, csub(mont_mul<SP>(ka.x, x.x, P), P.p), csub(mont_mul<SP>(ka.y, x.y, P), P.p));
 }
 
 // fHE::apply_galois (src/yell.cpp:14-24) as a gather through a per-galois index table; out-of-place.
-__global__ __launch_bounds__(PW_THREADS) void galois_gather_kernel(u64 *dst, const u64 *src, const u32 *perm, u64 N) {
+__global__ __launch_bounds__(PW_THREADS) void galois_gather_kernel(u64 *dst, const u64 *src, const u32 *perm, u64 N, u64 src_bstride,
+                                                                   u64 dst_bstride) {
   const u64 d = (u64)blockIdx.x * PW_THREADS + threadIdx.x;
-  const u64 o = ((u64)blockIdx.z * gridDim.y + blockIdx.y) * N;
-  dst[o + d] = src[o + perm[d]];
+  const u64 os = (u64)blockIdx.z * src_bstride + (u64)blockIdx.y * N, od = (u64)blockIdx.z * dst_bstride + (u64)blockIdx.y * N;
+  dst[od + d] = src[os + perm[d]];
 }
 __global__ void galois_perm_kernel(u32 *perm, u32 logN, u64 galois) {
   const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
