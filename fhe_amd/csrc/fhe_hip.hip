@@ -6,6 +6,7 @@
 #include "pointwise_kernels.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -203,6 +204,16 @@ int launch_cols(fhe_hip_ctx *c, const NttArgs &a, u32 nl, u32 batch) {
 template <bool SP, bool INV>
 int launch_rows(fhe_hip_ctx *c, const NttArgs &a, u32 nl, u32 batch) {
   const u32 R = 1u << c->logR, rows = R < 16 ? R : 16;
+  if constexpr (!INV) {
+    static const bool rows8 = [] { const char *e = getenv("FHE_HIP_ROWS8"); return e ? atoi(e) != 0 : true; }();
+    if (rows8 && R >= 8) {  // 8 elements per thread, 8 rows per workgroup
+      dim3 grid8(R / 8, nl, batch), block8(256);
+      if (a.epi == 1) { LAUNCH(c, "ntt_fwd_rows_rescale", (ntt_rows8_fwd_kernel<SP, 1>), grid8, block8, a); return FHE_HIP_OK; }
+      if (a.epi == 2) { LAUNCH(c, "ntt_fwd_rows_moddown", (ntt_rows8_fwd_kernel<SP, 2>), grid8, block8, a); return FHE_HIP_OK; }
+      LAUNCH(c, "ntt_fwd_rows", (ntt_rows8_fwd_kernel<SP, 0>), grid8, block8, a);
+      return FHE_HIP_OK;
+    }
+  }
   dim3 grid(R / rows, nl, batch), block(16 * rows);
   if constexpr (!INV) {
     if (a.epi == 1) { LAUNCH(c, "ntt_fwd_rows_rescale", (ntt_rows_kernel<SP, false, 1>), grid, block, a); return FHE_HIP_OK; }
@@ -350,6 +361,22 @@ int dev_rescale(fhe_hip_ctx *c, u64 *rop, const u64 *op, u32 n, u32 entries, int
 }
 
 // Mul::reLinearize: ct3 [b][3][Li][N] -> out [b][2][Li][N]
+// launch of the fused digit-NTT + key-MAC kernel: 8 elements per thread (more waves in flight) unless FHE_HIP_RELIN8=0 or R < 8
+int launch_relin(fhe_hip_ctx *c, RelinArgs &ra, u32 nb, u32 nout) {
+  const u32 R = 1u << c->logR;
+  static const bool relin8 = [] { const char *e = getenv("FHE_HIP_RELIN8"); return e ? atoi(e) != 0 : true; }();
+  ra.nb = nb;
+  if (relin8 && R >= 8) {
+    ra.rb_count = R / 8;
+    LAUNCH_SP(c, "relin_rows_mac", relin_rows8_mac_kernel, dim3(nb * (R / 8) * nout), dim3(256), ra);
+  } else {
+    const u32 rows = R < 16 ? R : 16;
+    ra.rb_count = R / rows;
+    LAUNCH_SP(c, "relin_rows_mac", relin_rows_mac_kernel, dim3(nb * (R / rows) * nout), dim3(16 * rows), ra);
+  }
+  return FHE_HIP_OK;
+}
+
 int dev_relin(fhe_hip_ctx *c, u64 *out, const u64 *ct3, u32 Li, u32 batch) {
   const u64 N = c->N;
   if (!c->d_mk_beta) FAIL(c, FHE_HIP_ERR_NOKEY, "mult key not loaded");
@@ -379,9 +406,7 @@ int dev_relin(fhe_hip_ctx *c, u64 *out, const u64 *ct3, u32 Li, u32 batch) {
     ra.beta_m = c->d_mk_beta; ra.alpha_m = c->d_mk_alpha; ra.klimbs = c->L;
     ra.tw = c->d_tw_fwd; ra.primes = c->d_primes; ra.omap = c->d_iota;
     ra.nd = Li; ra.nout = Li; ra.logN = c->logN; ra.logR = c->logR;
-    const u32 R = 1u << c->logR, rows = R < 16 ? R : 16;
-    ra.nb = nb; ra.rb_count = R / rows;
-    LAUNCH_SP(c, "relin_rows_mac", relin_rows_mac_kernel, dim3(nb * (R / rows) * Li), dim3(16 * rows), ra);
+    TRY(launch_relin(c, ra, nb, Li));
   }
   return FHE_HIP_OK;
 }
@@ -529,9 +554,7 @@ int dev_rotate_mixed(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch) {
   ra.beta_m = it->second.beta_m; ra.alpha_m = it->second.alpha_m; ra.klimbs = c->L + 1;
   ra.tw = c->d_tw_fwd; ra.primes = c->d_primes; ra.omap = omap;
   ra.nd = Li; ra.nout = nout; ra.logN = c->logN; ra.logR = c->logR;
-  const u32 R = 1u << c->logR, rows = R < 16 ? R : 16;
-  ra.nb = batch; ra.rb_count = R / rows;
-  LAUNCH_SP(c, "relin_rows_mac", relin_rows_mac_kernel, dim3(batch * (R / rows) * nout), dim3(16 * rows), ra);
+  TRY(launch_relin(c, ra, batch, nout));
   // rescale by the special prime (:475-515): entries = 2*batch polys of Li+1 limbs, last limb lives under P[L]
   NttPlan pl{ans + (size_t)Li * N, ans + (size_t)Li * N, c->d_iota + c->L, 1, 1, 1, 1, 2 * batch, (u64)nout * N, (u64)nout * N};
   TRY(ntt_run(c, pl, true));

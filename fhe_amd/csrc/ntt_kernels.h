@@ -210,6 +210,99 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row pass, 8 elements per thread (forward): 32 threads per 256-element row, three register phases of 3 + 3 + 2 stages.
+// Half the registers and half the LDS per thread of the 16-element version, so twice the waves per SIMD to hide the
+// global-memory latency.  LDS image per row: 8 chunks of 32 elements at chunk stride 36 (conflict-free strided reads).
+// ---------------------------------------------------------------------------------------------
+constexpr int ROW8_LDS = 8 * 36;
+__device__ __forceinline__ u32 row8_pos(u32 e) { return (e >> 5) * 36 + (e & 31); }
+
+template <bool SP, int EPI = 0>
+__global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
+  __shared__ __attribute__((aligned(16))) u64 lds[8 * ROW8_LDS];
+  const u32 tid = threadIdx.x, rloc = tid >> 5, t = tid & 31;
+  const u32 row = blockIdx.x * 8 + rloc;
+  const u32 l = blockIdx.y + a.l0, b = blockIdx.z;
+  const u32 m = a.midx[(l / a.mdiv) % a.mper];
+  const PrimeC P = a.primes[m];
+  const u64 N = 1ull << a.logN;
+  const u64 *__restrict__ tw = a.tw + (u64)m * N;
+  const u64 *s = a.src + (u64)b * a.src_bstride + (u64)(l % a.smod) * N + (u64)row * 256;
+  u64 *d = a.dst + (u64)b * a.dst_bstride + (u64)l * N + (u64)row * 256;
+  u64 *L = lds + rloc * ROW8_LDS;
+  const u32 baseA = (1u << a.logR) + row;
+  u64 e[8];
+  // phase A: spans 128, 64, 32; thread holds {t + 32k}
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = s[t + 32 * k];
+  fwd_phase<SP, 3>(e, tw, baseA, P);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) L[k * 36 + t] = e[k];
+  wave_lds_sync();
+  // phase B: spans 16, 8, 4 inside 32-element chunks; thread (c = t >> 2, r = t & 3) holds {32c + r + 4k}
+  const u32 c = t >> 2, r = t & 3;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = L[c * 36 + r + 4 * k];
+  fwd_phase<SP, 3>(e, tw, (baseA << 3) + c, P);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) L[c * 36 + r + 4 * k] = e[k];
+  wave_lds_sync();
+  // phase C: spans 2, 1; thread holds the 8 contiguous elements {8t + k} = two groups of four
+  {
+    const u32 p0 = row8_pos(8 * t);
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[p0 + k]);
+      e[k] = v.x; e[k + 1] = v.y;
+    }
+    u64 g0[4] = {e[0], e[1], e[2], e[3]}, g1[4] = {e[4], e[5], e[6], e[7]};
+    fwd_phase<SP, 2>(g0, tw, (baseA << 6) + 2 * t, P);
+    fwd_phase<SP, 2>(g1, tw, (baseA << 6) + 2 * t + 1, P);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { e[k] = g0[k]; e[4 + k] = g1[k]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = (EPI == 0) ? canon4(e[k], P) : csub(e[k], P.twop);
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) *reinterpret_cast<ulonglong2 *>(&L[p0 + k]) = make_ulonglong2(e[k], e[k + 1]);
+  }
+  wave_lds_sync();
+  // coalesced 16-byte stores: instruction i covers elements [64i, 64i + 64) of the row
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const u32 el = 64 * i + 2 * t;
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[row8_pos(el)]);
+    if constexpr (EPI == 0) {
+      *reinterpret_cast<ulonglong2 *>(&d[el]) = v;
+    } else {
+      const u64 off = (u64)l * N + (u64)row * 256 + el;
+      const ulonglong2 h = *reinterpret_cast<const ulonglong2 *>(&a.epi_src[(u64)b * a.epi_src_bstride + off]);
+      const u64 cm = a.epi_c[m];
+      u64 r0, r1;
+      if constexpr (EPI == 1) {
+        r0 = csub(mont_mul<SP>(cm, h.x + P.twop - v.x, P), P.p);
+        r1 = csub(mont_mul<SP>(cm, h.y + P.twop - v.y, P), P.p);
+      } else {
+        r0 = csub(mont_mul<SP>(cm, h.x + v.x, P), P.p);
+        r1 = csub(mont_mul<SP>(cm, h.y + v.y, P), P.p);
+        if (a.epi_add) {
+          ulonglong2 ad;
+          if (a.epi_add_perm) {
+            const u64 *al = a.epi_add + (u64)b * a.epi_add_bstride + (u64)l * N;
+            const uint2 pi = *reinterpret_cast<const uint2 *>(&a.epi_add_perm[row * 256 + el]);
+            ad = make_ulonglong2(al[pi.x], al[pi.y]);
+          } else {
+            ad = *reinterpret_cast<const ulonglong2 *>(&a.epi_add[(u64)b * a.epi_add_bstride + off]);
+          }
+          r0 = csub(r0 + ad.x, P.p); r1 = csub(r1 + ad.y, P.p);
+        }
+      }
+      *reinterpret_cast<ulonglong2 *>(&a.epi_out[(u64)b * a.epi_out_bstride + off]) = make_ulonglong2(r0, r1);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Column pass: LOGR stages over rows (stride 256 elements).  Tile = R rows x CT columns in LDS
 // ([R][CT+1]); threads = R*CT/16.  Two register phases: LA = max(LOGR-4,0) stages on rows
 // {g + (R>>LA) k}, then LB = min(LOGR,4) stages on rows {(u << LB) + k}; inverse runs them mirrored
@@ -413,6 +506,114 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const u32 e = 32 * q + 2 * t;
+    u64 r00 = csub(acc0[2 * q], P.p), r01 = csub(acc0[2 * q + 1], P.p), r10 = csub(acc1[2 * q], P.p), r11 = csub(acc1[2 * q + 1], P.p);
+    if (c0) { const ulonglong2 d0 = *reinterpret_cast<const ulonglong2 *>(&c0[e]); r00 = csub(r00 + d0.x, P.p); r01 = csub(r01 + d0.y, P.p); }
+    if (c1) { const ulonglong2 d1 = *reinterpret_cast<const ulonglong2 *>(&c1[e]); r10 = csub(r10 + d1.x, P.p); r11 = csub(r11 + d1.y, P.p); }
+    *reinterpret_cast<ulonglong2 *>(&o[e]) = make_ulonglong2(r00, r01);
+    *reinterpret_cast<ulonglong2 *>(&o[half + e]) = make_ulonglong2(r10, r11);
+  }
+}
+
+// 8-elements-per-thread version of relin_rows_mac_kernel (32 threads per row, 8 rows per workgroup): half the accumulator and
+// data registers per thread, so more waves per SIMD to hide the digit and key load latency (the 16-element kernel is held to
+// 3 waves by its 64 accumulator registers).  Same arguments, grid = nout * (R/8) * nb workgroups of 256 threads.
+template <bool SP>
+__global__ __launch_bounds__(256) void relin_rows8_mac_kernel(RelinArgs a) {
+  __shared__ __attribute__((aligned(16))) u64 lds[8 * ROW8_LDS];
+  const u32 tid = threadIdx.x, rloc = tid >> 5, t = tid & 31;
+  u32 rb, b, i;
+  {
+    const u32 id = blockIdx.x, nb = a.nb, RB = a.rb_count;
+    if ((RB & 7) == 0) {
+      const u32 xcd = id & 7, q = id >> 3;
+      b = q % nb;
+      const u32 rest = q / nb;
+      rb = xcd + 8 * (rest % (RB >> 3));
+      i = rest / (RB >> 3);
+    } else {
+      b = id % nb;
+      rb = (id / nb) % RB;
+      i = id / (nb * RB);
+    }
+  }
+  const u32 row = rb * 8 + rloc;
+  const u32 nd = a.nd;
+  const u32 m = a.omap[i];
+  const PrimeC P = a.primes[m];
+  const u64 N = 1ull << a.logN;
+  const u64 *__restrict__ tw = a.tw + (u64)m * N;
+  u64 *L = lds + rloc * ROW8_LDS;
+  const u32 baseA = (1u << a.logR) + row;
+  const u64 row_off = (u64)row * 256;
+  const u32 c = t >> 2, r = t & 3, p0 = row8_pos(8 * t);
+  u64 acc0[8], acc1[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { acc0[k] = 0; acc1[k] = 0; }
+  for (u32 j = 0; j < nd; ++j) {
+    u64 x[8];
+    if (j == i) {
+      const u64 *s = a.diag + (u64)b * a.diag_bstride + (u64)i * N + row_off;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&s[64 * q + 2 * t]);
+        x[2 * q] = v.x; x[2 * q + 1] = v.y;
+      }
+    } else {
+      const u64 *s = a.t1 + (((u64)b * a.nout + i) * nd + j) * N + row_off;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = s[t + 32 * k];
+      fwd_phase<SP, 3>(x, tw, baseA, P);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) L[k * 36 + t] = x[k];
+      wave_lds_sync();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = L[c * 36 + r + 4 * k];
+      fwd_phase<SP, 3>(x, tw, (baseA << 3) + c, P);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) L[c * 36 + r + 4 * k] = x[k];
+      wave_lds_sync();
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[p0 + k]);
+        x[k] = v.x; x[k + 1] = v.y;
+      }
+      {
+        u64 g0[4] = {x[0], x[1], x[2], x[3]}, g1[4] = {x[4], x[5], x[6], x[7]};
+        fwd_phase<SP, 2>(g0, tw, (baseA << 6) + 2 * t, P);
+        fwd_phase<SP, 2>(g1, tw, (baseA << 6) + 2 * t + 1, P);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { x[k] = g0[k]; x[4 + k] = g1[k]; }
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) *reinterpret_cast<ulonglong2 *>(&L[p0 + k]) = make_ulonglong2(x[k], x[k + 1]);
+      wave_lds_sync();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[row8_pos(64 * q + 2 * t)]);
+        x[2 * q] = v.x; x[2 * q + 1] = v.y;
+      }
+      wave_lds_sync();
+    }
+    // key MAC in the coalesced layout: lane t owns elements {64q + 2t, 64q + 2t + 1}; x may be lazy (< 4p)
+    const u64 koff = ((u64)j * a.klimbs + m) * N + row_off;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(&a.beta_m[koff + 64 * q + 2 * t]);
+      const ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(&a.alpha_m[koff + 64 * q + 2 * t]);
+      acc0[2 * q] = csub(acc0[2 * q] + mont_mul<SP>(kb.x, x[2 * q], P), P.twop);
+      acc0[2 * q + 1] = csub(acc0[2 * q + 1] + mont_mul<SP>(kb.y, x[2 * q + 1], P), P.twop);
+      acc1[2 * q] = csub(acc1[2 * q] + mont_mul<SP>(ka.x, x[2 * q], P), P.twop);
+      acc1[2 * q + 1] = csub(acc1[2 * q + 1] + mont_mul<SP>(ka.y, x[2 * q + 1], P), P.twop);
+    }
+  }
+  const u64 half = (u64)a.nout * N;
+  u64 *o = a.out + ((u64)b * 2 * a.nout + i) * N + row_off;
+  const u64 *c0 = a.add0 ? a.add0 + (u64)b * a.add_bstride + (u64)i * N + row_off : nullptr;
+  const u64 *c1 = a.add1 ? a.add1 + (u64)b * a.add_bstride + (u64)i * N + row_off : nullptr;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const u32 e = 64 * q + 2 * t;
     u64 r00 = csub(acc0[2 * q], P.p), r01 = csub(acc0[2 * q + 1], P.p), r10 = csub(acc1[2 * q], P.p), r11 = csub(acc1[2 * q + 1], P.p);
     if (c0) { const ulonglong2 d0 = *reinterpret_cast<const ulonglong2 *>(&c0[e]); r00 = csub(r00 + d0.x, P.p); r01 = csub(r01 + d0.y, P.p); }
     if (c1) { const ulonglong2 d1 = *reinterpret_cast<const ulonglong2 *>(&c1[e]); r10 = csub(r10 + d1.x, P.p); r11 = csub(r11 + d1.y, P.p); }

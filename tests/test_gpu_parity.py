@@ -421,3 +421,37 @@ def test_rotate_mixed_rot_key(logN, L, K, Li, sp):
     assert np.array_equal(host(d), ct)
     with pytest.raises(fhe_amd.FheHipError):
         g.rotate_mixed(5, d, Li, batch=B)
+
+
+def test_sixteen_element_row_kernels_still_match(tmp_path):
+    """The 16-elements-per-thread forward row pass and fused relinearisation kernel are kept behind FHE_HIP_ROWS8=0 /
+    FHE_HIP_RELIN8=0 (read once per process): run them in a child process against the oracle."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import numpy as np, torch, fhe_amd
+        from oracle import oracle as orc
+        logN, L, K, Li = 12, 3, 1, 3
+        pr, ps = orc.gen_primes(logN, L + K)
+        o, g = orc.Oracle(logN, L, K, pr, ps), fhe_amd.HipContext(logN, L, K, pr, ps)
+        rng = np.random.default_rng(5)
+        poly = lambda: np.stack([rng.integers(0, int(pr[i]), o.N, dtype=np.uint64) for i in range(Li)])
+        x = poly(); idx = list(range(Li))
+        d = torch.from_numpy(x.view(np.int64)).cuda()
+        g.ntt_forward(d, idx)
+        assert np.array_equal(d.cpu().numpy().view(np.uint64), o.ntt_forward(x.copy(), idx))
+        sx, ext = o.keygen_sk(seed=1)
+        beta, alpha = o.keygen_mult(sx, seed=2)
+        g.load_mult_key(torch.from_numpy(beta.view(np.int64)).cuda(), torch.from_numpy(alpha.view(np.int64)).cuda())
+        c0 = np.stack([poly(), poly()]); c1 = np.stack([poly(), poly()])
+        wb, wa = o.mul_relin_rescale(c0[0], c0[1], c1[0], c1[1], beta, alpha)
+        out = torch.zeros((1, 2, Li - 1, o.N), dtype=torch.int64, device="cuda")
+        g.mul_relin_rescale(out, torch.from_numpy(c0.view(np.int64)).cuda(), torch.from_numpy(c1.view(np.int64)).cuda(), Li, batch=1)
+        h = out.cpu().numpy().view(np.uint64)
+        assert np.array_equal(h[0, 0], wb) and np.array_equal(h[0, 1], wa)
+        print("legacy kernels OK")
+    ''')
+    env = dict(os.environ, FHE_HIP_ROWS8="0", FHE_HIP_RELIN8="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "legacy kernels OK" in r.stdout, r.stdout + r.stderr
