@@ -368,7 +368,7 @@ int launch_relin(fhe_hip_ctx *c, RelinArgs &ra, u32 nb, u32 nout) {
   ra.nb = nb;
   if (relin8 && R >= 8) {
     ra.rb_count = R / 8;
-    LAUNCH_SP(c, "relin_rows_mac", relin_rows8_mac_kernel, dim3(nb * (R / 8) * nout), dim3(256), ra);
+    LAUNCH_SP(c, "relin_rows_mac", relin_rows8p_mac_kernel, dim3(nb * (R / 8) * nout), dim3(256), ra);
   } else {
     const u32 rows = R < 16 ? R : 16;
     ra.rb_count = R / rows;

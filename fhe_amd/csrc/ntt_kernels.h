@@ -514,12 +514,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 }
 
-// 8-elements-per-thread version of relin_rows_mac_kernel (32 threads per row, 8 rows per workgroup): half the accumulator and
-// data registers per thread, so more waves per SIMD to hide the digit and key load latency (the 16-element kernel is held to
-// 3 waves by its 64 accumulator registers).  Same arguments, grid = nout * (R/8) * nb workgroups of 256 threads.
+// 8-elements-per-thread, latency-hiding version of relin_rows_mac_kernel (32 threads per row, 8 rows per workgroup; same
+// arguments, grid = nout * (R/8) * nb workgroups of 256 threads).  Vector-memory loads return in issue order (one vmcnt
+// counter), so a prefetch only hides latency if everything issued before it is also consumed before it.  Here issue order ==
+// consumption order: inside the key MAC of digit j the kernel requests digit j+1 (when x has been parked in the row image in
+// LDS, from which the MAC reads its operands), then keys_{j+1}[groups 0,1] once MAC groups 0,1 have used keys_j[0,1], then
+// keys_{j+1}[2,3]; the NTT of a digit issues no vector-memory loads at all (its 255 twiddles per row are read from an LDS copy
+// made once per workgroup, heap order: entry (1 << s) + g = stage s, group g).  16 + 32 VGPRs of loads stay in flight across
+// an NTT or a MAC; measured 6 % faster than the same kernel without the ordering, which waits for the newest load.
 template <bool SP>
-__global__ __launch_bounds__(256) void relin_rows8_mac_kernel(RelinArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void relin_rows8p_mac_kernel(RelinArgs a) {
   __shared__ __attribute__((aligned(16))) u64 lds[8 * ROW8_LDS];
+  __shared__ __attribute__((aligned(16))) u64 twl[8 * 256];
   const u32 tid = threadIdx.x, rloc = tid >> 5, t = tid & 31;
   u32 rb, b, i;
   {
@@ -541,34 +547,72 @@ __global__ __launch_bounds__(256) void relin_rows8_mac_kernel(RelinArgs a) {
   const u32 m = a.omap[i];
   const PrimeC P = a.primes[m];
   const u64 N = 1ull << a.logN;
-  const u64 *__restrict__ tw = a.tw + (u64)m * N;
   u64 *L = lds + rloc * ROW8_LDS;
+  u64 *T = twl + rloc * 256;
   const u32 baseA = (1u << a.logR) + row;
   const u64 row_off = (u64)row * 256;
   const u32 c = t >> 2, r = t & 3, p0 = row8_pos(8 * t);
+  {
+    const u64 *tw = a.tw + (u64)m * N;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const u32 idx = t + 32 * k;
+      if (idx) { const u32 st = 31 - __clz(idx); T[idx] = tw[((u64)(baseA - 1) << st) + idx]; }
+    }
+  }
+  wave_lds_sync();
   u64 acc0[8], acc1[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { acc0[k] = 0; acc1[k] = 0; }
+  u64 x[8];
+  // both kinds of digit are requested with the same eight strided loads {t + 32k} (one code path: the wait counters of the
+  // prefetch stay exact); the diagonal digit is ct[2] limb i itself and skips the NTT
+  auto load_digit = [&](u32 j) {
+    const u64 *s = (j == i) ? a.diag + (u64)b * a.diag_bstride + (u64)i * N + row_off
+                            : a.t1 + (((u64)b * a.nout + i) * nd + j) * N + row_off;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = s[t + 32 * k];
+  };
+  ulonglong2 kb[4], ka[4];
+  auto load_keys = [&](u32 j, int q0) {  // two MAC groups (q0, q0 + 1) of digit j
+    const u64 koff = ((u64)j * a.klimbs + m) * N + row_off;
+#pragma unroll
+    for (int q = q0; q < q0 + 2; ++q) {
+      kb[q] = *reinterpret_cast<const ulonglong2 *>(&a.beta_m[koff + 64 * q + 2 * t]);
+      ka[q] = *reinterpret_cast<const ulonglong2 *>(&a.alpha_m[koff + 64 * q + 2 * t]);
+    }
+  };
+  auto mac = [&](int q) {
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[row8_pos(64 * q + 2 * t)]);
+    acc0[2 * q] = csub(acc0[2 * q] + mont_mul<SP>(kb[q].x, v.x, P), P.twop);
+    acc0[2 * q + 1] = csub(acc0[2 * q + 1] + mont_mul<SP>(kb[q].y, v.y, P), P.twop);
+    acc1[2 * q] = csub(acc1[2 * q] + mont_mul<SP>(ka[q].x, v.x, P), P.twop);
+    acc1[2 * q + 1] = csub(acc1[2 * q + 1] + mont_mul<SP>(ka[q].y, v.y, P), P.twop);
+  };
+  // issue order == consumption order everywhere: digit_0, keys_0[0..1], keys_0[2..3], then inside MAC_j: digit_{j+1},
+  // keys_{j+1}[0..1] (after MAC groups 0,1 have consumed keys_j[0..1]), keys_{j+1}[2..3] (after groups 2,3)
+  if (nd) {
+    __builtin_amdgcn_sched_barrier(0);
+    load_digit(0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_keys(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_keys(0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   for (u32 j = 0; j < nd; ++j) {
-    u64 x[8];
+    const u32 jn = j + 1 < nd ? j + 1 : j;  // the last digit re-requests itself (keeps one code path; results unused)
     if (j == i) {
-      const u64 *s = a.diag + (u64)b * a.diag_bstride + (u64)i * N + row_off;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&s[64 * q + 2 * t]);
-        x[2 * q] = v.x; x[2 * q + 1] = v.y;
-      }
+      for (int k = 0; k < 8; ++k) L[k * 36 + t] = x[k];
     } else {
-      const u64 *s = a.t1 + (((u64)b * a.nout + i) * nd + j) * N + row_off;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) x[k] = s[t + 32 * k];
-      fwd_phase<SP, 3>(x, tw, baseA, P);
+      fwd_phase<SP, 3>(x, T, 1u, P);
 #pragma unroll
       for (int k = 0; k < 8; ++k) L[k * 36 + t] = x[k];
       wave_lds_sync();
 #pragma unroll
       for (int k = 0; k < 8; ++k) x[k] = L[c * 36 + r + 4 * k];
-      fwd_phase<SP, 3>(x, tw, (baseA << 3) + c, P);
+      fwd_phase<SP, 3>(x, T, 8u + c, P);
 #pragma unroll
       for (int k = 0; k < 8; ++k) L[c * 36 + r + 4 * k] = x[k];
       wave_lds_sync();
@@ -579,33 +623,28 @@ __global__ __launch_bounds__(256) void relin_rows8_mac_kernel(RelinArgs a) {
       }
       {
         u64 g0[4] = {x[0], x[1], x[2], x[3]}, g1[4] = {x[4], x[5], x[6], x[7]};
-        fwd_phase<SP, 2>(g0, tw, (baseA << 6) + 2 * t, P);
-        fwd_phase<SP, 2>(g1, tw, (baseA << 6) + 2 * t + 1, P);
+        fwd_phase<SP, 2>(g0, T, 64u + 2 * t, P);
+        fwd_phase<SP, 2>(g1, T, 64u + 2 * t + 1, P);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { x[k] = g0[k]; x[4 + k] = g1[k]; }
       }
       wave_lds_sync();
 #pragma unroll
       for (int k = 0; k < 8; k += 2) *reinterpret_cast<ulonglong2 *>(&L[p0 + k]) = make_ulonglong2(x[k], x[k + 1]);
-      wave_lds_sync();
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[row8_pos(64 * q + 2 * t)]);
-        x[2 * q] = v.x; x[2 * q + 1] = v.y;
-      }
-      wave_lds_sync();
     }
-    // key MAC in the coalesced layout: lane t owns elements {64q + 2t, 64q + 2t + 1}; x may be lazy (< 4p)
-    const u64 koff = ((u64)j * a.klimbs + m) * N + row_off;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(&a.beta_m[koff + 64 * q + 2 * t]);
-      const ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(&a.alpha_m[koff + 64 * q + 2 * t]);
-      acc0[2 * q] = csub(acc0[2 * q] + mont_mul<SP>(kb.x, x[2 * q], P), P.twop);
-      acc0[2 * q + 1] = csub(acc0[2 * q + 1] + mont_mul<SP>(kb.y, x[2 * q + 1], P), P.twop);
-      acc1[2 * q] = csub(acc1[2 * q] + mont_mul<SP>(ka.x, x[2 * q], P), P.twop);
-      acc1[2 * q + 1] = csub(acc1[2 * q + 1] + mont_mul<SP>(ka.y, x[2 * q + 1], P), P.twop);
-    }
+    wave_lds_sync();
+    __builtin_amdgcn_sched_barrier(0);
+    load_digit(jn);
+    __builtin_amdgcn_sched_barrier(0);
+    mac(0); mac(1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_keys(jn, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mac(2); mac(3);
+    __builtin_amdgcn_sched_barrier(0);
+    load_keys(jn, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    wave_lds_sync();
   }
   const u64 half = (u64)a.nout * N;
   u64 *o = a.out + ((u64)b * 2 * a.nout + i) * N + row_off;
