@@ -174,7 +174,7 @@ struct NttPlan {
   u32 batch;
   u64 src_bstride, dst_bstride;
   u32 skip_diag = 0;
-  bool cols_only = false;  // forward only: stop after the column pass (the row pass is fused elsewhere)
+  bool cols_only = false;  // run the column pass only (the row pass is fused into another kernel)
   // forward only: epilogue fused into the row pass (NttArgs::epi); dst is then only the column-pass scratch
   u32 epi = 0;
   const u64 *epi_src = nullptr, *epi_c = nullptr, *epi_add = nullptr;
@@ -243,7 +243,7 @@ int ntt_run_sp(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
     TRY((launch_cols<SP, false>(c, first, p.nl, p.batch)));
     if (!p.cols_only) TRY((launch_rows<SP, false>(c, second, p.nl, p.batch)));
   } else {
-    TRY((launch_rows<SP, true>(c, first, p.nl, p.batch)));
+    if (!p.cols_only) TRY((launch_rows<SP, true>(c, first, p.nl, p.batch)));  // cols_only: the row pass was fused elsewhere
     TRY((launch_cols<SP, true>(c, second, p.nl, p.batch)));
   }
   return FHE_HIP_OK;
@@ -471,6 +471,8 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
            (const u32 *)perm, N, (u64)2 * Li * N, g_bstride);
   }
   const u64 *axg = fused ? ct + (size_t)Li * N : g + (size_t)Li * N;  // galois(ax), through perm when fused
+  static const bool sp_fusion = [] { const char *e = getenv("FHE_HIP_ROT_FUSED"); return e ? atoi(e) != 0 : true; }();
+  const bool fused_sp = sp_fusion && !non_ntt && c->logR >= 3;
   if (non_ntt) {
     // ax_g is already in the power basis (:537): mod up, then forward NTT of all Li+K limbs (:539-542)
     TRY(dev_conv_to_special(c, e0, nl, Li, g + (size_t)Li * N, 2 * Li, Li, batch));
@@ -486,24 +488,43 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
     // mod up: special limbs from the power basis; normal limbs of the NTT-domain result are ax_g itself
     // (NTT(INTT(x)) = x for canonical x, so the Li forward NTTs of :363-366 are not recomputed)
     TRY(dev_conv_to_special(c, e0, nl, Li, pw, Li, Li, batch));
-    // forward NTT of the K special limbs
+    // forward NTT of the K special limbs: column pass here; for R >= 8 the row pass, both key products and the row pass of
+    // the two inverse NTTs (:363-392 for cm >= Li) run fused in rot_special_rows8_kernel
     NttPlan pf{e0 + (size_t)Li * N, e0 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
+    pf.cols_only = fused_sp;
     TRY(ntt_run(c, pf, false));
   }
   const u32 *rotmap = c->d_rotmap + (size_t)Li * c->M;
-  LAUNCH_SP(c, "rot_keymul", rot_keymul_kernel, pw_grid(c, nl, batch), dim3(PW_THREADS), e0, e1, (const u64 *)e0, (const u64 *)it->second.beta_m,
-            (const u64 *)it->second.alpha_m, (const PrimeC *)c->d_primes, rotmap, nl, N,
-            (const u64 *)(non_ntt ? nullptr : axg), (u64)2 * Li * N, Li, (const u32 *)(fused ? perm : nullptr));  // NTT path: normal limbs straight from ax_g
-  if (non_ntt) {  // every limb back to the power basis (:563-567)
-    NttPlan p0{e0, e0, c->d_rotmap + (size_t)Li * c->M, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
-    TRY(ntt_run(c, p0, true));
-    NttPlan p1{e1, e1, c->d_rotmap + (size_t)Li * c->M, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
-    TRY(ntt_run(c, p1, true));
-  } else {  // special limbs back to the power basis (:386-392)
-    NttPlan p0{e0 + (size_t)Li * N, e0 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
-    TRY(ntt_run(c, p0, true));
-    NttPlan p1{e1 + (size_t)Li * N, e1 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
-    TRY(ntt_run(c, p1, true));
+  if (fused_sp) {
+    RotSpArgs ra;
+    ra.e0 = e0; ra.e1 = e1; ra.beta_m = it->second.beta_m; ra.alpha_m = it->second.alpha_m;
+    ra.tw_fwd = c->d_tw_fwd; ra.tw_inv = c->d_tw_inv; ra.primes = c->d_primes;
+    ra.first_mod = c->L; ra.first_limb = Li; ra.nl = nl; ra.logN = c->logN; ra.logR = c->logR;
+    LAUNCH_SP(c, "rot_special_rows", rot_special_rows8_kernel, dim3((1u << c->logR) / 8, K, batch), dim3(256), ra);
+    // key product of the Li normal limbs (read through the galois table when fused)
+    LAUNCH_SP(c, "rot_keymul", rot_keymul_kernel, pw_grid(c, Li, batch), dim3(PW_THREADS), e0, e1, (const u64 *)e0, (const u64 *)it->second.beta_m,
+              (const u64 *)it->second.alpha_m, (const PrimeC *)c->d_primes, rotmap, nl, N, axg, (u64)2 * Li * N, Li, (const u32 *)(fused ? perm : nullptr));
+    for (int h = 0; h < 2; ++h) {  // column pass of the inverse NTTs of the special limbs (:386-392)
+      u64 *e = (h == 0 ? e0 : e1) + (size_t)Li * N;
+      NttPlan pc{e, e, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
+      pc.cols_only = true;
+      TRY(ntt_run(c, pc, true));
+    }
+  } else {
+    LAUNCH_SP(c, "rot_keymul", rot_keymul_kernel, pw_grid(c, nl, batch), dim3(PW_THREADS), e0, e1, (const u64 *)e0, (const u64 *)it->second.beta_m,
+              (const u64 *)it->second.alpha_m, (const PrimeC *)c->d_primes, rotmap, nl, N,
+              (const u64 *)(non_ntt ? nullptr : axg), (u64)2 * Li * N, Li, (const u32 *)(fused ? perm : nullptr));  // NTT path: normal limbs straight from ax_g
+    if (non_ntt) {  // every limb back to the power basis (:563-567)
+      NttPlan p0{e0, e0, c->d_rotmap + (size_t)Li * c->M, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
+      TRY(ntt_run(c, p0, true));
+      NttPlan p1{e1, e1, c->d_rotmap + (size_t)Li * c->M, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
+      TRY(ntt_run(c, p1, true));
+    } else {  // special limbs back to the power basis (:386-392)
+      NttPlan p0{e0 + (size_t)Li * N, e0 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
+      TRY(ntt_run(c, p0, true));
+      NttPlan p1{e1 + (size_t)Li * N, e1 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
+      TRY(ntt_run(c, p1, true));
+    }
   }
   // mod down both halves straight into ct (strided [b][2][Li][N]); rop[0] += galois(bx) read from g (:394-398)
   TRY(ensure_ws(c, 2, (size_t)batch * Li * N * 8));

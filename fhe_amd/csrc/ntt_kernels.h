@@ -303,6 +303,100 @@ __global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Special-limb middle of the hybrid rotation key switch (reference src/evaluator.cpp:363-392), fused: finish the forward NTT of
+// an extended limb (row pass), multiply by the two key limbs, and run the row pass of both inverse NTTs, all on the same
+// 256-element rows in registers/LDS.  The thread that ends the forward pass with the 8 contiguous values {8t + k} is the one
+// that starts the inverse pass from them, so the two key products and the switch of direction need no exchange.
+// Replaces: forward row pass + key product + two inverse row passes (three round trips through HBM) for the K special limbs.
+// ---------------------------------------------------------------------------------------------
+struct RotSpArgs {
+  u64 *e0, *e1;                  // [b][nl][N]: e0 holds the column-pass output of the special limbs on entry
+  const u64 *beta_m, *alpha_m;   // [L+K][N] Montgomery form
+  const u64 *tw_fwd, *tw_inv;
+  const PrimeC *primes;
+  u32 first_mod;                 // modulus index of the first special limb (= L)
+  u32 first_limb;                // its limb position inside an entry (= Li)
+  u32 nl, logN, logR;
+};
+
+template <bool SP>
+__global__ __launch_bounds__(256) void rot_special_rows8_kernel(RotSpArgs a) {
+  __shared__ __attribute__((aligned(16))) u64 lds[8 * ROW8_LDS];
+  const u32 tid = threadIdx.x, rloc = tid >> 5, t = tid & 31;
+  const u32 row = blockIdx.x * 8 + rloc;
+  const u32 m = a.first_mod + blockIdx.y, b = blockIdx.z;
+  const PrimeC P = a.primes[m];
+  const u64 N = 1ull << a.logN;
+  const u64 *__restrict__ twf = a.tw_fwd + (u64)m * N;
+  const u64 *__restrict__ twi = a.tw_inv + (u64)m * N;
+  const u64 off = ((u64)b * a.nl + a.first_limb + blockIdx.y) * N + (u64)row * 256;
+  u64 *L = lds + rloc * ROW8_LDS;
+  const u32 baseA = (1u << a.logR) + row;
+  const u32 c = t >> 2, r = t & 3, p0 = row8_pos(8 * t);
+  u64 x[8];
+  // forward row pass (as ntt_rows8_fwd_kernel), result lazy in [0,4p), thread holds {8t + k}
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = a.e0[off + t + 32 * k];
+  fwd_phase<SP, 3>(x, twf, baseA, P);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) L[k * 36 + t] = x[k];
+  wave_lds_sync();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = L[c * 36 + r + 4 * k];
+  fwd_phase<SP, 3>(x, twf, (baseA << 3) + c, P);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) L[c * 36 + r + 4 * k] = x[k];
+  wave_lds_sync();
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[p0 + k]);
+    x[k] = v.x; x[k + 1] = v.y;
+  }
+  {
+    u64 g0[4] = {x[0], x[1], x[2], x[3]}, g1[4] = {x[4], x[5], x[6], x[7]};
+    fwd_phase<SP, 2>(g0, twf, (baseA << 6) + 2 * t, P);
+    fwd_phase<SP, 2>(g1, twf, (baseA << 6) + 2 * t + 1, P);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { x[k] = g0[k]; x[4 + k] = g1[k]; }
+  }
+  // two key products and two inverse row passes (spans 1..128), outputs lazy in [0,2p) as ntt_rows_kernel<INVERSE> leaves them
+  const u64 koff = (u64)m * N + (u64)row * 256 + 8 * t;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const u64 *key = (h == 0 ? a.beta_m : a.alpha_m) + koff;
+    u64 y[8];
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(&key[k]);
+      y[k] = mont_mul<SP>(kv.x, x[k], P); y[k + 1] = mont_mul<SP>(kv.y, x[k + 1], P);  // (0,2p)
+    }
+    {
+      u64 g0[4] = {y[0], y[1], y[2], y[3]}, g1[4] = {y[4], y[5], y[6], y[7]};
+      inv_phase<SP, 2>(g0, twi, (baseA << 6) + 2 * t, P);
+      inv_phase<SP, 2>(g1, twi, (baseA << 6) + 2 * t + 1, P);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { y[k] = g0[k]; y[4 + k] = g1[k]; }
+    }
+    wave_lds_sync();  // the row image may still be read by the previous exchange
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) *reinterpret_cast<ulonglong2 *>(&L[p0 + k]) = make_ulonglong2(y[k], y[k + 1]);
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y[k] = L[c * 36 + r + 4 * k];
+    inv_phase<SP, 3>(y, twi, (baseA << 3) + c, P);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) L[c * 36 + r + 4 * k] = y[k];
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y[k] = L[k * 36 + t];
+    inv_phase<SP, 3>(y, twi, baseA, P);
+    u64 *d = (h == 0 ? a.e0 : a.e1) + off;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d[t + 32 * k] = y[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Column pass: LOGR stages over rows (stride 256 elements).  Tile = R rows x CT columns in LDS
 // ([R][CT+1]); threads = R*CT/16.  Two register phases: LA = max(LOGR-4,0) stages on rows
 // {g + (R>>LA) k}, then LB = min(LOGR,4) stages on rows {(u << LB) + k}; inverse runs them mirrored

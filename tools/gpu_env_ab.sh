@@ -6,5 +6,5 @@ for wl in "$@"; do for v in 0 1; do
   export $var=$v
   timeout -k 10 150 python -u bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
-r=json.loads(sys.stdin.read()); print('$var=$v', '$wl', round(r['value'],1), {k:round(v['total_ms']/v['launches'],4) for k,v in r['kernel_ms'].items() if 'ntt' in k})" || exit 1
+r=json.loads(sys.stdin.read()); print('$var=$v', '$wl', round(r['value'],1), {k:round(v['total_ms']/v['launches'],4) for k,v in r['kernel_ms'].items() if 'ntt' in k or 'rot' in k})" || exit 1
 done; done
