@@ -51,6 +51,8 @@ struct fhe_hip_ctx {
   u64 *d_hat_pi_inv_m = nullptr;                 // [K]          mod p_k
   u64 *d_neg_hat_pi_qj_m = nullptr;              // [L][K]       mod q_l
   u64 *d_Pinv_qj_m = nullptr;                    // [L]          mod q_j
+  u64 *d_modup_scale_m = nullptr;                // [L-1][M]   N^-1 * hat_qj_inv[Li-2][j] mod q_j (row Li-2), Montgomery form
+  u64 *d_moddown_scale_m = nullptr;              // [M]        N^-1 * hat_pi_inv[k] mod p_k at index L+k, Montgomery form
   u64 *d_pow2w = nullptr;                        // [M][6]       2^w mod p, w = 0,21,42,32,53,74 (bconv fold)
   u64 *d_hat_qj_inv_m = nullptr;                 // [L-1][L]     mod q_j
   u64 *d_hat_qj_pi_m = nullptr;                  // [L-1][K][L]  mod p_k
@@ -180,6 +182,7 @@ struct NttPlan {
   const u64 *epi_src = nullptr, *epi_c = nullptr, *epi_add = nullptr;
   u64 *epi_out = nullptr;
   u64 epi_src_bstride = 0, epi_add_bstride = 0, epi_out_bstride = 0;
+  const u64 *inv_scale = nullptr;     // inverse only: per-modulus factor replacing N^-1 in the column pass (NttArgs::inv_scale)
   const u32 *perm = nullptr;          // inverse only: gather the source through a galois index table
   const u32 *epi_add_perm = nullptr;  // gather the epilogue addend through a galois index table
 };
@@ -233,7 +236,7 @@ int ntt_run_sp(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
   a.dst = p.dst; a.dst_bstride = p.dst_bstride;
   a.epi = inverse ? 0 : p.epi; a.epi_src = p.epi_src; a.epi_c = p.epi_c; a.epi_add = p.epi_add; a.epi_out = p.epi_out;
   a.epi_src_bstride = p.epi_src_bstride; a.epi_add_bstride = p.epi_add_bstride; a.epi_out_bstride = p.epi_out_bstride;
-  a.perm = nullptr; a.epi_add_perm = p.epi_add_perm;
+  a.perm = nullptr; a.epi_add_perm = p.epi_add_perm; a.inv_scale = inverse ? p.inv_scale : nullptr;
   // first pass reads the (possibly broadcast) source, second pass runs in place on dst
   NttArgs first = a, second = a;
   first.src = p.src; first.src_bstride = p.src_bstride; first.smod = p.smod;
@@ -306,7 +309,7 @@ int check_ctx(fhe_hip_ctx *c) {
 // ---- device pipelines (all pointers device) ------------------------------------------------------
 
 // BaseConverter::approximated_mod_up body on device: special limbs of rop from power-basis op
-int dev_conv_to_special(fhe_hip_ctx *c, u64 *rop, u32 rop_limbs, u32 rop_off, const u64 *op, u32 op_limbs, u32 Li, u32 batch) {
+int dev_conv_to_special(fhe_hip_ctx *c, u64 *rop, u32 rop_limbs, u32 rop_off, const u64 *op, u32 op_limbs, u32 Li, u32 batch, bool pre_scaled = false) {
   BconvArgs a;
   a.out = rop; a.src = op;
   a.inv_m = c->d_hat_qj_inv_m + (size_t)(Li - 2) * c->L;
@@ -315,11 +318,14 @@ int dev_conv_to_special(fhe_hip_ctx *c, u64 *rop, u32 rop_limbs, u32 rop_off, co
   a.nsrc = Li; a.src_first = 0; a.src_limbs = op_limbs; a.src_off = 0;
   a.tgt_first = c->L; a.out_limbs = rop_limbs; a.out_off = rop_off; a.hat_stride = c->L; a.ntgt = c->K;
   a.N = c->N;
-  LAUNCH_SP(c, "bconv_modup", bconv_kernel, dim3((unsigned)(c->N / PW_THREADS), (c->K + BCONV_TC - 1) / BCONV_TC, batch), dim3(PW_THREADS), a);
+  const dim3 grid((unsigned)(c->N / PW_THREADS), (c->K + BCONV_TC - 1) / BCONV_TC, batch);
+  // pre_scaled: op already holds the digits [x_k * inv_k]_{q_k} (the producing inverse NTT was scaled by N^-1 * inv_k)
+  if (pre_scaled) { if (c->sp) LAUNCH(c, "bconv_modup", (bconv_kernel<true, true>), grid, dim3(PW_THREADS), a); else LAUNCH(c, "bconv_modup", (bconv_kernel<false, true>), grid, dim3(PW_THREADS), a); }
+  else { if (c->sp) LAUNCH(c, "bconv_modup", (bconv_kernel<true, false>), grid, dim3(PW_THREADS), a); else LAUNCH(c, "bconv_modup", (bconv_kernel<false, false>), grid, dim3(PW_THREADS), a); }
   return FHE_HIP_OK;
 }
 // neg_approx_convert_to_normal_basis for j < L0: special limbs (power basis) at limb offset sp_off of op
-int dev_conv_to_normal(fhe_hip_ctx *c, u64 *rop, u32 L0, const u64 *op, u32 op_limbs, u32 sp_off, u32 batch) {
+int dev_conv_to_normal(fhe_hip_ctx *c, u64 *rop, u32 L0, const u64 *op, u32 op_limbs, u32 sp_off, u32 batch, bool pre_scaled = false) {
   BconvArgs a;
   a.out = rop; a.src = op;
   a.inv_m = c->d_hat_pi_inv_m;
@@ -328,7 +334,9 @@ int dev_conv_to_normal(fhe_hip_ctx *c, u64 *rop, u32 L0, const u64 *op, u32 op_l
   a.nsrc = c->K; a.src_first = c->L; a.src_limbs = op_limbs; a.src_off = sp_off;
   a.tgt_first = 0; a.out_limbs = L0; a.out_off = 0; a.hat_stride = c->K; a.ntgt = L0;
   a.N = c->N;
-  LAUNCH_SP(c, "bconv_moddown", bconv_kernel, dim3((unsigned)(c->N / PW_THREADS), (L0 + BCONV_TC - 1) / BCONV_TC, batch), dim3(PW_THREADS), a);
+  const dim3 grid((unsigned)(c->N / PW_THREADS), (L0 + BCONV_TC - 1) / BCONV_TC, batch);
+  if (pre_scaled) { if (c->sp) LAUNCH(c, "bconv_moddown", (bconv_kernel<true, true>), grid, dim3(PW_THREADS), a); else LAUNCH(c, "bconv_moddown", (bconv_kernel<false, true>), grid, dim3(PW_THREADS), a); }
+  else { if (c->sp) LAUNCH(c, "bconv_moddown", (bconv_kernel<true, false>), grid, dim3(PW_THREADS), a); else LAUNCH(c, "bconv_moddown", (bconv_kernel<false, false>), grid, dim3(PW_THREADS), a); }
   return FHE_HIP_OK;
 }
 
@@ -484,10 +492,11 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
     // power basis of ax_g (d[1]->backward(), :360)
     NttPlan pi{axg, pw, c->d_iota, 1, Li, Li, Li, batch, (u64)2 * Li * N, (u64)Li * N};
     pi.perm = fused ? perm : nullptr;
+    pi.inv_scale = c->d_modup_scale_m + (size_t)(Li - 2) * c->M;  // pw = base-conversion digits [ax * hat_inv]_q, not ax itself
     TRY(ntt_run(c, pi, true));
     // mod up: special limbs from the power basis; normal limbs of the NTT-domain result are ax_g itself
     // (NTT(INTT(x)) = x for canonical x, so the Li forward NTTs of :363-366 are not recomputed)
-    TRY(dev_conv_to_special(c, e0, nl, Li, pw, Li, Li, batch));
+    TRY(dev_conv_to_special(c, e0, nl, Li, pw, Li, Li, batch, true));
     // forward NTT of the K special limbs: column pass here; for R >= 8 the row pass, both key products and the row pass of
     // the two inverse NTTs (:363-392 for cm >= Li) run fused in rot_special_rows8_kernel
     NttPlan pf{e0 + (size_t)Li * N, e0 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
@@ -507,7 +516,7 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
     for (int h = 0; h < 2; ++h) {  // column pass of the inverse NTTs of the special limbs (:386-392)
       u64 *e = (h == 0 ? e0 : e1) + (size_t)Li * N;
       NttPlan pc{e, e, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
-      pc.cols_only = true;
+      pc.cols_only = true; pc.inv_scale = c->d_moddown_scale_m;  // special limbs come out as mod-down digits
       TRY(ntt_run(c, pc, true));
     }
   } else {
@@ -521,8 +530,10 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
       TRY(ntt_run(c, p1, true));
     } else {  // special limbs back to the power basis (:386-392)
       NttPlan p0{e0 + (size_t)Li * N, e0 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
+      p0.inv_scale = c->d_moddown_scale_m;
       TRY(ntt_run(c, p0, true));
       NttPlan p1{e1 + (size_t)Li * N, e1 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
+      p1.inv_scale = c->d_moddown_scale_m;
       TRY(ntt_run(c, p1, true));
     }
   }
@@ -531,7 +542,7 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
   u64 *conv = (u64 *)c->ws[2];
   for (int h = 0; h < 2; ++h) {
     const u64 *op = h == 0 ? e0 : e1;
-    TRY(dev_conv_to_normal(c, conv, Li, op, nl, Li, batch));
+    TRY(dev_conv_to_normal(c, conv, Li, op, nl, Li, batch, !non_ntt));
     NttPlan p{conv, conv, c->d_iota, 1, Li, Li, Li, batch, (u64)Li * N, (u64)Li * N};
     p.epi = 2; p.epi_src = op; p.epi_src_bstride = (u64)nl * N; p.epi_c = c->d_Pinv_qj_m;
     p.epi_add = h == 0 ? g : nullptr; p.epi_add_bstride = g_bstride;
@@ -669,6 +680,14 @@ int fhe_hip_ctx_create(fhe_hip_ctx **out, uint32_t logN, uint32_t L, uint32_t K,
   for (uint32_t a = 0; a < M; ++a)
     for (uint32_t j = 0; j < M; ++j)
       if (a != j) qinv[(size_t)a * M + j] = h_to_mont(h_invmod(P[a] % P[j], P[j]), P[j]);  // math::inv_mod_prime(P[a], j), base_converter.cpp:261
+  // inverse-NTT scale factors with the base-conversion digit constants folded in (the digits then cost nothing extra)
+  std::vector<u64> modup_scale(Lm1 * M, 0), moddown_scale(M, 0);
+  for (uint32_t n = 2; n <= L; ++n)
+    for (uint32_t j = 0; j < n; ++j)
+      modup_scale[(size_t)(n - 2) * M + j] = h_to_mont(h_mulmod(h_invmod(N % P[j], P[j]), h_invmod(h_product_of(P, 0, n, (int)j, j), P[j]), P[j]), P[j]);
+  for (uint32_t k = 0; k < K; ++k)
+    moddown_scale[L + k] = h_to_mont(h_mulmod(h_invmod(N % P[L + k], P[L + k]), h_invmod(h_product_of(P, L, K, (int)k, L + k), P[L + k]), P[L + k]), P[L + k]);
+  if ((rc = upload(c, &c->d_modup_scale_m, modup_scale)) || (rc = upload(c, &c->d_moddown_scale_m, moddown_scale))) return fail(rc);
   std::vector<u64> pow2w((size_t)M * 6);
   for (uint32_t m = 0; m < M; ++m)
     for (int w = 0; w < 6; ++w) pow2w[(size_t)m * 6 + w] = h_powmod(2, (u64)kBconvWeights[w], P[m]);
@@ -686,7 +705,7 @@ void fhe_hip_ctx_destroy(fhe_hip_ctx *c) {
   hipDeviceSynchronize();
   prof_drain(c);
   void *ptrs[] = {c->d_primes, c->d_tw_fwd, c->d_tw_inv, c->d_iota, c->d_rotmap, c->d_hat_pi_inv_m, c->d_neg_hat_pi_qj_m, c->d_Pinv_qj_m,
-                  c->d_hat_qj_inv_m, c->d_hat_qj_pi_m, c->d_qinv_m, c->d_mk_beta, c->d_mk_alpha, c->d_pow2w};
+                  c->d_hat_qj_inv_m, c->d_hat_qj_pi_m, c->d_qinv_m, c->d_mk_beta, c->d_mk_alpha, c->d_pow2w, c->d_modup_scale_m, c->d_moddown_scale_m};
   for (void *p : ptrs) if (p) hipFree(p);
   for (auto &kv : c->rot_keys) { hipFree(kv.second.beta_m); hipFree(kv.second.alpha_m); }
   for (auto &kv : c->mixed_keys) { hipFree(kv.second.beta_m); hipFree(kv.second.alpha_m); }

@@ -30,6 +30,7 @@ struct NttArgs {
   //   epi == 1: out = (src + 2p - t) * c mod p          BaseConverter::rescale inner loop (src/base_converter.cpp:264-271)
   //   epi == 2: out = (src + t) * c [+ add] mod p       tail of approximated_mod_down (:227-240) [+ evaluator.cpp:398]
   // src/add/out = [b](bstride)[limb][N] addressed by the same (b, limb) as the NTT; c[modulus index] in Montgomery form.
+  const u64 *inv_scale;  // inverse column pass only: [M] Montgomery-form factors used instead of N^-1 (N^-1 times a constant the consumer needs)
   const u32 *perm;   // inverse row pass only: element d of a limb is read from src[perm[d]] (fHE::apply_galois fused into the load)
   const u32 *epi_add_perm;  // same for the epilogue addend
   u32 epi;
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs
   const u32 col0 = blockIdx.x * CT;
   const u64 *s = a.src + (u64)b * a.src_bstride + (u64)(l % a.smod) * N + col0;
   u64 *d = a.dst + (u64)b * a.dst_bstride + (u64)l * N + col0;
+  const u64 nscale = (INVERSE && a.inv_scale) ? a.inv_scale[m] : P.ninv_m;
 
   if constexpr (!INVERSE) {
     if constexpr (LA > 0) {
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs
       for (int k = 0; k < (1 << LB); ++k) {
         const u32 row = (u << LB) + k;
         if constexpr (LA > 0) lds[row * CS + c] = e[k];
-        else d[(u64)row * 256 + c] = csub(mont_mul<SP>(P.ninv_m, e[k], P), P.p);
+        else d[(u64)row * 256 + c] = csub(mont_mul<SP>(nscale, e[k], P), P.p);
       }
     }
     if constexpr (LA > 0) {
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs
         for (int k = 0; k < (1 << LA); ++k) e[k] = lds[(g + G * k) * CS + c];
         inv_phase<SP, LA>(e, tw, 1u, P);
 #pragma unroll
-        for (int k = 0; k < (1 << LA); ++k) d[(u64)(g + G * k) * 256 + c] = csub(mont_mul<SP>(P.ninv_m, e[k], P), P.p);
+        for (int k = 0; k < (1 << LA); ++k) d[(u64)(g + G * k) * 256 + c] = csub(mont_mul<SP>(nscale, e[k], P), P.p);
       }
     }
   }

@@ -74,7 +74,7 @@ struct BconvArgs {
 // hat is in Montgomery form, so mont(2^w mod p, acc_w) = acc_w' * 2^w mod p of the plain sum.
 #define BCONV_TC 6
 __device__ constexpr int kBconvWeights[6] = {0, 21, 42, 32, 53, 74};
-template <bool SP>
+template <bool SP, bool PRE = false>
 __global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
   const u64 d = (u64)blockIdx.x * PW_THREADS + threadIdx.x;
   const u32 tbase = blockIdx.y * BCONV_TC, e = blockIdx.z;
@@ -89,8 +89,10 @@ __global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
     for (int w = 0; w < 6; ++w) acc[t][w] = 0;
   }
   for (u32 k = 0; k < a.nsrc; ++k) {
-    const PrimeC PS = a.primes[a.src_first + k];
-    const u64 t0 = csub(mont_mul<SP>(a.inv_m[k], sp[(u64)k * a.N], PS), PS.p);  // canonical residue mod the source prime
+    [[maybe_unused]] const PrimeC PS = a.primes[a.src_first + k];
+    const u64 xk = sp[(u64)k * a.N];
+    u64 t0;  // canonical digit [x_k * inv_k] mod the source prime
+    if constexpr (PRE) t0 = xk; else t0 = csub(mont_mul<SP>(a.inv_m[k], xk, PS), PS.p);
     const u32 b0 = (u32)t0, b1 = (u32)(t0 >> 32);
 #pragma unroll
     for (int t = 0; t < BCONV_TC; ++t) {
