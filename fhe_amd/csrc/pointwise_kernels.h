@@ -72,7 +72,7 @@ struct BconvArgs {
 // 21-bit limbs) times t0 (two 32-bit words) gives six partial products < 2^53, each added into its own 64-bit
 // accumulator by one v_mad_u64_u32 (room for 2^10 terms).  The six accumulators are folded once per target at the end:
 // hat is in Montgomery form, so mont(2^w mod p, acc_w) = acc_w' * 2^w mod p of the plain sum.
-#define BCONV_TC 6
+#define BCONV_TC 5
 __device__ constexpr int kBconvWeights[6] = {0, 21, 42, 32, 53, 74};
 template <bool SP, bool PRE = false>
 __global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
