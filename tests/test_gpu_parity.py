@@ -455,3 +455,46 @@ def test_sixteen_element_row_kernels_still_match(tmp_path):
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0 and "legacy kernels OK" in r.stdout, r.stdout + r.stderr
+
+
+def _uniform(o, idx, rng):
+    return np.stack([rng.integers(0, int(o.primes[i]), o.N, dtype=np.uint64) for i in idx])
+
+
+def test_config3_full_size_bit_exact():
+    """BASELINE config 3 at full size (N=2^16, Li=L=30): one multiply + relinearize + rescale, every output limb equal to the
+    CPU oracle's.  Keys are uniform polynomials (computationally what real keys are): the arithmetic does not care."""
+    logN, L, K, Li = 16, 30, 1, 30
+    o, g = ctx_pair(logN, L, K)
+    rng = np.random.default_rng(33)
+    beta = np.stack([_uniform(o, range(L), rng) for _ in range(L)])
+    alpha = np.stack([_uniform(o, range(L), rng) for _ in range(L)])
+    c0 = np.stack([_uniform(o, range(Li), rng), _uniform(o, range(Li), rng)])
+    c1 = np.stack([_uniform(o, range(Li), rng), _uniform(o, range(Li), rng)])
+    wb, wa = o.mul_relin_rescale(c0[0], c0[1], c1[0], c1[1], beta, alpha)
+    g.load_mult_key(dev(beta), dev(alpha))
+    out = torch.zeros((2, 2, Li - 1, o.N), dtype=torch.int64, device="cuda")
+    both0, both1 = np.stack([c0, c1]), np.stack([c1, c0])  # batch of two: (c0*c1) and (c1*c0) must agree as well
+    g.mul_relin_rescale(out, dev(both0), dev(both1), Li, batch=2)
+    h = host(out)
+    assert np.array_equal(h[0, 0], wb) and np.array_equal(h[0, 1], wa)
+    assert np.array_equal(h[1], h[0])
+    del beta, alpha
+    g.close(); _ctx_cache.pop((logN, L, K, True), None)
+
+
+def test_config4_full_size_bit_exact():
+    """BASELINE config 4 at full size (N=2^16, Li=L=K=30): one rotation key switch equal to the CPU oracle's, limb for limb."""
+    logN, L, K, Li = 16, 30, 30, 30
+    o, g = ctx_pair(logN, L, K)
+    rng = np.random.default_rng(44)
+    gal = o.rotation_galois(1)
+    rkb, rka = _uniform(o, range(L + K), rng), _uniform(o, range(L + K), rng)
+    ct = np.stack([_uniform(o, range(Li), rng), _uniform(o, range(Li), rng)])
+    wb, wa = o.rotate(ct[0], ct[1], gal, rkb, rka)
+    g.load_rot_key(gal, dev(rkb), dev(rka))
+    d = dev(np.stack([ct, ct]))
+    g.rotate(gal, d, Li, batch=2)
+    h = host(d)
+    assert np.array_equal(h[0, 0], wb) and np.array_equal(h[0, 1], wa) and np.array_equal(h[1], h[0])
+    g.close(); _ctx_cache.pop((logN, L, K, True), None)
