@@ -217,6 +217,13 @@ int launch_rows(fhe_hip_ctx *c, const NttArgs &a, u32 nl, u32 batch) {
       return FHE_HIP_OK;
     }
   }
+  if constexpr (INV) {
+    static const bool rows8i = [] { const char *e = getenv("FHE_HIP_ROWS8_INV"); return e ? atoi(e) != 0 : true; }();
+    if (rows8i && R >= 8) {
+      LAUNCH(c, "ntt_inv_rows", (ntt_rows8_inv_kernel<SP>), dim3(R / 8, nl, batch), dim3(256), a);
+      return FHE_HIP_OK;
+    }
+  }
   dim3 grid(R / rows, nl, batch), block(16 * rows);
   if constexpr (!INV) {
     if (a.epi == 1) { LAUNCH(c, "ntt_fwd_rows_rescale", (ntt_rows_kernel<SP, false, 1>), grid, block, a); return FHE_HIP_OK; }

@@ -303,6 +303,67 @@ __global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
   }
 }
 
+// Row pass of the inverse NTT, 8 elements per thread (mirror of ntt_rows8_fwd_kernel): spans 1, 2 | 4, 8, 16 | 32, 64, 128;
+// coalesced 16-byte loads (optionally gathered through a galois index table), output lazy in [0,2p) for the column pass.
+template <bool SP>
+__global__ __launch_bounds__(256) void ntt_rows8_inv_kernel(NttArgs a) {
+  __shared__ __attribute__((aligned(16))) u64 lds[8 * ROW8_LDS];
+  const u32 tid = threadIdx.x, rloc = tid >> 5, t = tid & 31;
+  const u32 row = blockIdx.x * 8 + rloc;
+  const u32 l = blockIdx.y + a.l0, b = blockIdx.z;
+  const u32 m = a.midx[(l / a.mdiv) % a.mper];
+  const PrimeC P = a.primes[m];
+  const u64 N = 1ull << a.logN;
+  const u64 *__restrict__ tw = a.tw + (u64)m * N;
+  const u64 *s = a.src + (u64)b * a.src_bstride + (u64)(l % a.smod) * N + (u64)row * 256;
+  u64 *d = a.dst + (u64)b * a.dst_bstride + (u64)l * N + (u64)row * 256;
+  u64 *L = lds + rloc * ROW8_LDS;
+  const u32 baseA = (1u << a.logR) + row;
+  const u32 c = t >> 2, r = t & 3, p0 = row8_pos(8 * t);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const u32 el = 64 * i + 2 * t;
+    ulonglong2 v;
+    if (a.perm) {
+      const u64 *sl = s - (u64)row * 256;  // limb base
+      const uint2 pi = *reinterpret_cast<const uint2 *>(&a.perm[row * 256 + el]);
+      v = make_ulonglong2(sl[pi.x], sl[pi.y]);
+    } else {
+      v = *reinterpret_cast<const ulonglong2 *>(&s[el]);
+    }
+    *reinterpret_cast<ulonglong2 *>(&L[row8_pos(el)]) = v;
+  }
+  wave_lds_sync();
+  u64 e[8];
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[p0 + k]);
+    e[k] = v.x; e[k + 1] = v.y;
+  }
+  {
+    u64 g0[4] = {e[0], e[1], e[2], e[3]}, g1[4] = {e[4], e[5], e[6], e[7]};
+    inv_phase<SP, 2>(g0, tw, (baseA << 6) + 2 * t, P);
+    inv_phase<SP, 2>(g1, tw, (baseA << 6) + 2 * t + 1, P);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { e[k] = g0[k]; e[4 + k] = g1[k]; }
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) *reinterpret_cast<ulonglong2 *>(&L[p0 + k]) = make_ulonglong2(e[k], e[k + 1]);
+  wave_lds_sync();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = L[c * 36 + r + 4 * k];
+  inv_phase<SP, 3>(e, tw, (baseA << 3) + c, P);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) L[c * 36 + r + 4 * k] = e[k];
+  wave_lds_sync();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = L[k * 36 + t];
+  inv_phase<SP, 3>(e, tw, baseA, P);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) d[t + 32 * k] = e[k];
+}
+
 // ---------------------------------------------------------------------------------------------
 // Special-limb middle of the hybrid rotation key switch (reference src/evaluator.cpp:363-392), fused: finish the forward NTT of
 // an extended limb (row pass), multiply by the two key limbs, and run the row pass of both inverse NTTs, all on the same

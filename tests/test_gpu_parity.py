@@ -439,6 +439,8 @@ def test_sixteen_element_row_kernels_still_match(tmp_path):
         d = torch.from_numpy(x.view(np.int64)).cuda()
         g.ntt_forward(d, idx)
         assert np.array_equal(d.cpu().numpy().view(np.uint64), o.ntt_forward(x.copy(), idx))
+        g.ntt_backward(d, idx)
+        assert np.array_equal(d.cpu().numpy().view(np.uint64), x)
         sx, ext = o.keygen_sk(seed=1)
         beta, alpha = o.keygen_mult(sx, seed=2)
         g.load_mult_key(torch.from_numpy(beta.view(np.int64)).cuda(), torch.from_numpy(alpha.view(np.int64)).cuda())
@@ -450,7 +452,7 @@ def test_sixteen_element_row_kernels_still_match(tmp_path):
         assert np.array_equal(h[0, 0], wb) and np.array_equal(h[0, 1], wa)
         print("legacy kernels OK")
     ''')
-    env = dict(os.environ, FHE_HIP_ROWS8="0", FHE_HIP_RELIN8="0")
+    env = dict(os.environ, FHE_HIP_ROWS8="0", FHE_HIP_RELIN8="0", FHE_HIP_ROWS8_INV="0")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
