@@ -500,3 +500,42 @@ def test_config4_full_size_bit_exact():
     h = host(d)
     assert np.array_equal(h[0, 0], wb) and np.array_equal(h[0, 1], wa) and np.array_equal(h[1], h[0])
     g.close(); _ctx_cache.pop((logN, L, K, True), None)
+
+
+@pytest.mark.parametrize("logN,L,K,Li,B", [(13, 6, 2, 5, 3), (14, 4, 4, 2, 2), (15, 3, 1, 3, 1), (13, 9, 3, 9, 2)])
+def test_shape_sweep_relin_and_rotate(logN, L, K, Li, B):
+    """Ragged shapes at mid sizes: Li < L, odd batches, K != L; multiply+relin+rescale and both rotation variants vs the oracle."""
+    o, g = ctx_pair(logN, L, K)
+    rng = np.random.default_rng(logN * 100 + Li)
+    beta = np.stack([_uniform(o, range(L), rng) for _ in range(L)])
+    alpha = np.stack([_uniform(o, range(L), rng) for _ in range(L)])
+    g.load_mult_key(dev(beta), dev(alpha))
+    c0 = np.stack([np.stack([_uniform(o, range(Li), rng), _uniform(o, range(Li), rng)]) for _ in range(B)])
+    c1 = np.stack([np.stack([_uniform(o, range(Li), rng), _uniform(o, range(Li), rng)]) for _ in range(B)])
+    out = torch.zeros((B, 2, Li - 1, o.N), dtype=torch.int64, device="cuda")
+    g.mul_relin_rescale(out, dev(c0), dev(c1), Li, batch=B)
+    h = host(out)
+    for b in range(B):
+        wb, wa = o.mul_relin_rescale(c0[b, 0], c0[b, 1], c1[b, 0], c1[b, 1], beta, alpha)
+        assert np.array_equal(h[b, 0], wb) and np.array_equal(h[b, 1], wa)
+    gal = o.rotation_galois(2)
+    rkb, rka = _uniform(o, range(L + K), rng), _uniform(o, range(L + K), rng)
+    g.load_rot_key(gal, dev(rkb), dev(rka))
+    d = dev(c0)
+    g.rotate(gal, d, Li, batch=B)
+    h = host(d)
+    for b in range(B):
+        wb, wa = o.rotate(c0[b, 0], c0[b, 1], gal, rkb, rka)
+        assert np.array_equal(h[b, 0], wb) and np.array_equal(h[b, 1], wa)
+    mb = np.stack([_uniform(o, range(L + 1), rng) for _ in range(L)])
+    ma = np.stack([_uniform(o, range(L + 1), rng) for _ in range(L)])
+    # key limb L of a MixedRotKey lives under the special prime P[L]
+    for i in range(L):
+        mb[i, L] %= np.uint64(int(o.primes[L])); ma[i, L] %= np.uint64(int(o.primes[L]))
+    g.load_mixed_rot_key(gal, dev(mb), dev(ma))
+    d = dev(c1)
+    g.rotate_mixed(gal, d, Li, batch=B)
+    h = host(d)
+    for b in range(B):
+        wb, wa = o.rotate_mixed(c1[b, 0], c1[b, 1], gal, mb, ma)
+        assert np.array_equal(h[b, 0], wb) and np.array_equal(h[b, 1], wa)
