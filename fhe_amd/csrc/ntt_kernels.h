@@ -48,6 +48,14 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 __device__ __forceinline__ u64 canon4(u64 v, const PrimeC &P) { return csub(csub(v, P.twop), P.p); }
 
+// acc + k*x*2^-64 (mod p) with acc kept lazy in [0,4p); k < p in Montgomery form, x < 4p + 2^32
+template <bool SP>
+__device__ __forceinline__ u64 lazy_acc(u64 acc, u64 k, u64 x, const PrimeC &P) {
+  const u64 xp = (acc >= P.twop) ? acc - P.p : acc + P.p;
+  if constexpr (SP) return xp + mont_diff<true>(k, x, P);
+  else return xp + (mont_mul<false>(k, x, P) - P.p);
+}
+
 template <bool SP, int LK>
 __device__ __forceinline__ void fwd_phase(u64 (&e)[1 << LK], const u64 *__restrict__ tw, u32 base, const PrimeC &P) {
 #pragma unroll
@@ -741,10 +749,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   };
   auto mac = [&](int q) {
     const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[row8_pos(64 * q + 2 * t)]);
-    acc0[2 * q] = csub(acc0[2 * q] + mont_mul<SP>(kb[q].x, v.x, P), P.twop);
-    acc0[2 * q + 1] = csub(acc0[2 * q + 1] + mont_mul<SP>(kb[q].y, v.y, P), P.twop);
-    acc1[2 * q] = csub(acc1[2 * q] + mont_mul<SP>(ka[q].x, v.x, P), P.twop);
-    acc1[2 * q + 1] = csub(acc1[2 * q + 1] + mont_mul<SP>(ka[q].y, v.y, P), P.twop);
+    // accumulators stay lazy in [0,4p) like the X side of a butterfly: acc' = ((acc mod 2p) + p) + D, D in (-p, p)
+    acc0[2 * q] = lazy_acc<SP>(acc0[2 * q], kb[q].x, v.x, P);
+    acc0[2 * q + 1] = lazy_acc<SP>(acc0[2 * q + 1], kb[q].y, v.y, P);
+    acc1[2 * q] = lazy_acc<SP>(acc1[2 * q], ka[q].x, v.x, P);
+    acc1[2 * q + 1] = lazy_acc<SP>(acc1[2 * q + 1], ka[q].y, v.y, P);
   };
   // issue order == consumption order everywhere: digit_0, keys_0[0..1], keys_0[2..3], then inside MAC_j: digit_{j+1},
   // keys_{j+1}[0..1] (after MAC groups 0,1 have consumed keys_j[0..1]), keys_{j+1}[2..3] (after groups 2,3)
@@ -810,7 +819,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const u32 e = 64 * q + 2 * t;
-    u64 r00 = csub(acc0[2 * q], P.p), r01 = csub(acc0[2 * q + 1], P.p), r10 = csub(acc1[2 * q], P.p), r11 = csub(acc1[2 * q + 1], P.p);
+    u64 r00 = canon4(acc0[2 * q], P), r01 = canon4(acc0[2 * q + 1], P), r10 = canon4(acc1[2 * q], P), r11 = canon4(acc1[2 * q + 1], P);
     if (c0) { const ulonglong2 d0 = *reinterpret_cast<const ulonglong2 *>(&c0[e]); r00 = csub(r00 + d0.x, P.p); r01 = csub(r01 + d0.y, P.p); }
     if (c1) { const ulonglong2 d1 = *reinterpret_cast<const ulonglong2 *>(&c1[e]); r10 = csub(r10 + d1.x, P.p); r11 = csub(r11 + d1.y, P.p); }
     *reinterpret_cast<ulonglong2 *>(&o[e]) = make_ulonglong2(r00, r01);
