@@ -49,6 +49,13 @@ template <bool SP>
 __device__ __forceinline__ u64 mont_mul(u64 a, u64 b, const PrimeC &P);
 
 __device__ __forceinline__ u64 csub(u64 x, u64 m) { return x >= m ? x - m : x; }
+// same for a modulus the compiler holds in scalar registers (a field of the workgroup's PrimeC): the subtraction becomes one
+// 64-bit add of -m, kept opaque so that it is not turned back into a two-instruction borrow chain
+__device__ __forceinline__ u64 csub_u(u64 x, u64 m) {
+  u64 negm = 0 - m;
+  asm("" : "+s"(negm));
+  return x >= m ? x + negm : x;
+}
 
 // exact a*b mod p in [0,p); a < p, b < 2^64 (two Montgomery steps: a*b/R, then * R^2/R)
 template <bool SP>
@@ -186,6 +193,6 @@ template <bool SP>
 __device__ __forceinline__ void gs_bfly(u64 &X, u64 &Y, u64 W, const PrimeC &P) {
   const u64 s = X + Y;
   const u64 d = X - Y + P.twop;
-  X = csub(s, P.twop);
+  X = csub_u(s, P.twop);
   Y = mont_diff<SP>(W, d, P) + P.p;
 }

@@ -46,7 +46,7 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ u64 canon4(u64 v, const PrimeC &P) { return csub(csub(v, P.twop), P.p); }
+__device__ __forceinline__ u64 canon4(u64 v, const PrimeC &P) { return csub_u(csub_u(v, P.twop), P.p); }
 
 // acc + k*x*2^-64 (mod p) with acc kept lazy in [0,4p); k < p in Montgomery form, x < 4p + 2^32
 template <bool SP>
