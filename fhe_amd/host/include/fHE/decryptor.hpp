@@ -1,11 +1,11 @@
 // fHE/decryptor.hpp — polynomial-level decrypt of reference src/decryptor.cpp:11-38 (the integer
-// "decrypted-plaintext" parity probe).  The Encoder-based overloads (:40-78) are out of the hot path.
+// "decrypted-plaintext" parity probe).  The Encoder overloads (:40-78) decode on the host (fHE/encoder.hpp).
 #pragma once
 #include "fHE/cipher.hpp"
+#include "fHE/encoder.hpp"
 #include "fHE/keys.hpp"
 #include "fHE/yell.hpp"
 namespace fHE {
-struct Encoder;
 struct Decryptor {
   explicit Decryptor(std::shared_ptr<Encoder> encoder = nullptr) : encoder(encoder) {}
   ~Decryptor() {}
@@ -26,8 +26,25 @@ struct Decryptor {
     rop->backward();
     return true;
   }
+  bool decrypt(std::vector<std::complex<double>> *rop, Cipher const &ctx, SK const &sk) const { return decrypt_values(rop, ctx, sk); }  // :40-50
+  bool decrypt(std::vector<double> *rop, Cipher const &ctx, SK const &sk) const { return decrypt_values(rop, ctx, sk); }  // :52-61
+  bool decrypt(double *rop, Cipher const &ctx, SK const &sk) const {  // :63-77
+    if (!rop) return false;
+    std::vector<double> val;
+    if (!decrypt(&val, ctx, sk)) return false;
+    *rop = val[0];
+    return true;
+  }
 
  private:
+  template <class V>
+  bool decrypt_values(V *rop, Cipher const &ctx, SK const &sk) const {
+    if (!rop || !encoder) return false;
+    context::poly_t plain(ctx.moduli_count());
+    if (!decrypt(&plain, ctx, sk)) return false;
+    encoder->decode(rop, plain, ctx.scale());
+    return true;
+  }
   std::shared_ptr<Encoder> encoder;
 };
 }  // namespace fHE

@@ -1,10 +1,10 @@
 // fHE/encryptor.hpp — polynomial-level encrypt of reference src/encryptor.cpp:9-37 (host plumbing; NTTs on the GPU).
-// The floating-point Encoder overloads (encryptor.cpp:39-64) are out of the hot path and not provided.
+// The Encoder overloads (encryptor.cpp:39-64) encode on the host (fHE/encoder.hpp) and then take the same path.
 #pragma once
 #include "fHE/cipher.hpp"
+#include "fHE/encoder.hpp"
 #include "fHE/keys.hpp"
 namespace fHE {
-struct Encoder;
 struct Encryptor {
   explicit Encryptor(std::shared_ptr<Encoder> encoder = nullptr) : encoder(encoder) {}
   ~Encryptor() {}
@@ -31,8 +31,19 @@ struct Encryptor {
     rop->ax.add_product_of(u, pk.ax);  // ctx.ax = u * pk.ax + e1
     return true;
   }
+  bool encrypt(Cipher *rop, double const &value, PK const &pk) const { return encrypt(rop, std::vector<double>(1, value), pk); }  // :39-42
+  bool encrypt(Cipher *rop, std::vector<double> const &values, PK const &pk) const { return encrypt_values(rop, values, pk); }  // :44-52
+  bool encrypt(Cipher *rop, std::vector<std::complex<double>> const &values, PK const &pk) const { return encrypt_values(rop, values, pk); }  // :54-64
 
  private:
+  template <class V>
+  bool encrypt_values(Cipher *rop, V const &values, PK const &pk) const {
+    if (!rop || !encoder) return false;
+    context::poly_t plain(context::nr_ctxt_moduli);
+    encoder->encode(&plain, values, context::encoder_scale);
+    rop->scale(context::encoder_scale);
+    return encrypt(rop, plain, pk);
+  }
   std::shared_ptr<Encoder> encoder;
 };
 }  // namespace fHE

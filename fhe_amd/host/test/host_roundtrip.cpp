@@ -31,9 +31,9 @@ int main(int argc, char **argv) {
     fHE::PK pk(sk);
     fHE::MultKey mkey(sk);
     fHE::RotKey rkey(sk, 1, fHE::RotKey::Direction::LEFT);
-    fHE::Encryptor encryptor;
-    fHE::Decryptor decryptor;
     auto encoder = std::make_shared<fHE::Encoder>();
+    fHE::Encryptor encryptor(encoder);
+    fHE::Decryptor decryptor(encoder);
     fHE::Evaluator evaluator(encoder);
 
     // integer plaintexts a, b with small coefficients times 2^40
@@ -121,6 +121,30 @@ int main(int argc, char **argv) {
     if (!evaluator.replicate(&rep, rep_pos, rset)) { std::fprintf(stderr, "replicate failed\n"); return 15; }
     fHE::context::poly_t rep_mask(L);
     { std::vector<double> mask(nr_slots, 0.); mask[rep_pos] = 1.; encoder->encode(&rep_mask, mask, fHE::context::encoder_scale / 8.); }
+
+    // CKKS end to end through the Encoder overloads (reference main.cpp flow): slot values in, slot values out.
+    // decode(decrypt(x (*) y)) ~ x[i]*y[i]; decode(decrypt(rotate_left_1(x))) ~ x[i+1]
+    {
+      std::vector<double> xs(nr_slots), ys(nr_slots), got;
+      for (size_t i = 0; i < nr_slots; ++i) { xs[i] = std::sin(0.37 * (double)i) * 1.5; ys[i] = std::cos(0.11 * (double)i) - 0.5; }
+      fHE::Cipher cx, cy;
+      if (!encryptor.encrypt(&cx, xs, pk) || !encryptor.encrypt(&cy, ys, pk)) { std::fprintf(stderr, "encrypt(values) failed\n"); return 16; }
+      fHE::Cipher cr(cx);
+      if (!evaluator.multiply_and_relin(&cx, cy, mkey) || !decryptor.decrypt(&got, cx, sk)) { std::fprintf(stderr, "value multiply failed\n"); return 17; }
+      double mul_err = 0;
+      for (size_t i = 0; i < nr_slots; ++i) mul_err = std::max(mul_err, std::fabs(got[i] - xs[i] * ys[i]));
+      std::printf("slot-wise product max error: %.3e (scale after rescale 2^%.2f)\n", mul_err, std::log2(cx.scale()));
+      if (!(mul_err < 1e-6)) { std::fprintf(stderr, "slot-wise product too inaccurate\n"); return 18; }
+      if (K >= L) {  // hybrid key switching is only low-noise when P >= Q (the reference fixes K = L)
+        if (!evaluator.rotate_slots(&cr, rkey) || !decryptor.decrypt(&got, cr, sk)) { std::fprintf(stderr, "value rotate failed\n"); return 19; }
+        double rot_err = 0;
+        for (size_t i = 0; i < nr_slots; ++i) rot_err = std::max(rot_err, std::fabs(got[i] - xs[(i + 1) % nr_slots]));
+        std::printf("slot rotation max error: %.3e\n", rot_err);
+        if (!(rot_err < 1e-6)) { std::fprintf(stderr, "slot rotation too inaccurate\n"); return 20; }
+        double one = 0;
+        if (!decryptor.decrypt(&one, cr, sk) || std::fabs(one - xs[1]) > 1e-6) { std::fprintf(stderr, "decrypt(double) wrong\n"); return 21; }
+      }
+    }
 
     FILE *f = std::fopen(path, "wb");
     if (!f) { std::perror("fopen"); return 9; }
