@@ -4,12 +4,14 @@
 // checker and compare bit for bit.   usage: host_roundtrip <logN> <L> <K> <dump-file>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
 #include "fHE/context.hpp"
 #include "fHE/cipher.hpp"
 #include "fHE/decryptor.hpp"
 #include "fHE/encoder.hpp"
 #include "fHE/encryptor.hpp"
 #include "fHE/evaluator.hpp"
+#include "fHE/wire.hpp"
 
 using T = yell::params::value_type;
 static void dump(FILE *f, const char *name, fHE::context::poly_t const &p) {
@@ -165,6 +167,17 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i + 1 < logN; ++i) { auto k = rset.get((uint16_t)(1u << i)); dump(f, "rs_beta", k->beta); dump(f, "rs_alpha", k->alpha); }
     dump(f, "rep_mask", rep_mask); dump(f, "rep_bx", rep.bx); dump(f, "rep_ax", rep.ax);
     std::fclose(f);
+    // the multiplied ciphertext and the rotation key once more in the limb-dump wire format (fHE/wire.hpp), read back here
+    {
+      const std::string wpath = std::string(path) + ".wire";
+      { std::ofstream os(wpath, std::ios::binary); fHE::wire::write_cipher(os, ca); fHE::wire::write_key(os, {&rkey.beta, &rkey.alpha}, rkey.galois); }
+      std::ifstream is(wpath, std::ios::binary);
+      fHE::Cipher back_ct(1);
+      fHE::wire::read_cipher(is, &back_ct);
+      if (back_ct.moduli_count() != ca.moduli_count() || back_ct.scale() != ca.scale() ||
+          std::memcmp(back_ct.bx.cptr_at(0), ca.bx.cptr_at(0), ca.moduli_count() * N * 8) ||
+          std::memcmp(back_ct.ax.cptr_at(0), ca.ax.cptr_at(0), ca.moduli_count() * N * 8)) { std::fprintf(stderr, "wire round trip differs\n"); return 22; }
+    }
     std::printf("host_roundtrip OK\n");
     return 0;
   } catch (std::exception const &e) {

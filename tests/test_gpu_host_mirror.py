@@ -11,6 +11,7 @@ import pytest
 
 from oracle import oracle as orc
 from oracle.encoder import EncoderOracle
+from fhe_amd import wire
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "fhe_amd", "host", "bin", "host_roundtrip")
@@ -56,6 +57,15 @@ def test_config1_roundtrip_through_cpp_api(tmp_path, logN, L, K):
     # ciphertext-limb level
     ob, oa = o.mul_relin_rescale(a_bx, a_ax, b_bx, b_ax, beta, alpha)
     assert np.array_equal(d["mul_bx"][0], ob) and np.array_equal(d["mul_ax"][0], oa)
+    # the same ciphertext and the rotation key as written by fHE/wire.hpp (limb-dump wire format)
+    with open(path + ".wire", "rb") as f:
+        meta, ct = wire.load(f)
+        kmeta, key = wire.load(f)
+    assert meta["kind"] == wire.CIPHER and meta["n_limbs"] == L - 1 and not meta["has_mul_aux"] and meta["ntt"]
+    assert np.array_equal(ct[0], ob) and np.array_equal(ct[1], oa)
+    assert meta["scale"] == 2.0 ** 40 / int(o.primes[L - 1]) * 2.0 ** 40
+    assert kmeta["kind"] == wire.KEY and kmeta["galois"] == galois
+    assert np.array_equal(key[0], d["rk_beta"][0]) and np.array_equal(key[1], d["rk_alpha"][0])
     # decrypted-plaintext level
     assert np.array_equal(d["dec_mul"][0], o.decrypt(ob, oa, sx))
     rb, ra = o.rotate(a_bx, a_ax, galois, d["rk_beta"][0], d["rk_alpha"][0])
