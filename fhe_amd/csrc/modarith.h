@@ -90,6 +90,19 @@ __device__ __forceinline__ u64 mad_op(u32 a, u32 b, u64 c) {
   return d;
 }
 __device__ __forceinline__ u64 pair64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+// a*b + (2^32 - 1), the addend in a scalar pair: the high word is then h0 + (T0 != 0) and the low word T0 - 1
+__device__ __forceinline__ u64 mad_op_k(u32 a, u32 b) {
+  u64 d, cc;
+  const u64 k = 0xFFFFFFFFull;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cc) : "v"(a), "v"(b), "s"(k));
+  return d;
+}
+// x >> 32 as one 64-bit shift (the compiler's own lowering moves the word and zeroes the other: two instructions)
+__device__ __forceinline__ u64 hi_word(u64 x) {
+  u64 d;
+  asm("v_lshrrev_b64 %0, 32, %1" : "=v"(d) : "v"(x));
+  return d;
+}
 
 // Reference formulation of mont_diff (kept for tools/ubench/bfly.hip and the generic-prime path).
 template <bool SP>
@@ -131,17 +144,16 @@ __device__ __forceinline__ u64 mad_op_carry(u32 a, u32 b, u64 c, u32 &carry) {
 //   step 1 (additive):  q0 = -T0 mod 2^32, c0 = (T0 != 0):
 //        V = (T + q0*p) / 2^32 - a1*b1*2^32 = (h0 + c0) + a1*b0 + q0*p1 + a0*b1              (65 bits: V2:V1:V0)
 //   step 2 (subtractive): V - V0*p has a zero low word:  D = a1*b1 + (V2:V1) - V0*p1.
-// 6 multiply-adds + 3 carry-word operations + 3 plain ones (the product-then-reduce form compiles to 6 + 18).
+// c0 comes for free as the carry of adding 2^32 - 1 inside the first multiply-add.
+// 6 multiply-adds + 2 carry-word operations + 4 plain ones (the product-then-reduce form compiles to 6 + 18).
 template <bool SP>
 __device__ __forceinline__ u64 mont_diff(u64 a, u64 b, const PrimeC &P) {
   if constexpr (SP) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u32 p1 = P.p1;
-    const u64 t0 = mad_op0(a0, b0);
-    const u32 T0 = (u32)t0;
-    const u32 hlo = (u32)(t0 >> 32) + min(T0, 1u);        // h0 <= 2^32 - 2: no carry
-    const u64 t1 = mad_op(a1, b0, pair64(hlo, 0u));       // < 2^62 + 2^32
-    const u64 m = mad_op(0u - T0, p1, t1);                // < 2^63 + 2^32
+    const u64 t0 = mad_op_k(a0, b0);                      // a0*b0 + 2^32 - 1 <= 2^64 - 2^32: (T0 - 1, h0 + c0)
+    const u64 t1 = mad_op(a1, b0, hi_word(t0));           // < 2^62 + 2^32
+    const u64 m = mad_op(~(u32)t0, p1, t1);               // q0 = -T0 = ~(T0 - 1);  < 2^63 + 2^32
     u32 V2, w1, w2;
     const u64 t2 = mad_op_carry(a0, b1, m, V2);
     const u32 V0 = (u32)t2, V1 = (u32)(t2 >> 32);

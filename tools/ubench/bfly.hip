@@ -15,28 +15,13 @@
 template <int V> __device__ __forceinline__ void bf(u64 &X, u64 &Y, u64 W, const PrimeC &P);
 template <> __device__ __forceinline__ void bf<0>(u64 &X, u64 &Y, u64 W, const PrimeC &P) { ct_bfly_ref<true>(X, Y, W, P); }
 template <> __device__ __forceinline__ void bf<1>(u64 &X, u64 &Y, u64 W, const PrimeC &P) { ct_bfly<true>(X, Y, W, P); }
-// variant 2 = variant 1 with the 2p reduction of X decided on the high word by plain 32-bit VOP2 operations
-// (values then live in [0, 4p + 2^32))
-__device__ __forceinline__ u64 xp_fast(u64 X, const PrimeC &P) {
-  const int dd = (int)(2u * P.p1 - (u32)(X >> 32));  // < 0  <=>  X.hi > 2*p1  =>  subtract p, else add p
-  const u32 mask = (u32)(dd >> 31);
-  return X + pair64(mask | 1u, P.p1 ^ mask);
-}
-template <> __device__ __forceinline__ void bf<2>(u64 &X, u64 &Y, u64 W, const PrimeC &P) {
-  const u64 D = mont_diff<true>(W, Y, P);
-  const u64 xp = xp_fast(X, P);
-  X = xp + D;
-  Y = xp - D;
-}
-// variant 3 = variant 2 with q0 / c0 through plain VOP2 operations
-__device__ __forceinline__ u64 mont_diff_v3(u64 a, u64 b, const PrimeC &P) {
+// variant 2 = the formulation before the "+ 2^32 - 1" addend: q0 by negation, c0 by its borrow, (hlo, 0) by a move
+__device__ __forceinline__ u64 mont_diff_v2(u64 a, u64 b, const PrimeC &P) {
   const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
   const u32 p1 = P.p1;
   const u64 t0 = mad_op0(a0, b0);
   const u32 T0 = (u32)t0;
-  u32 c0;
-  asm("v_min_u32 %0, 1, %1" : "=v"(c0) : "v"(T0));
-  const u32 hlo = (u32)(t0 >> 32) + c0;
+  const u32 hlo = (u32)(t0 >> 32) + min(T0, 1u);
   const u64 t1 = mad_op(a1, b0, pair64(hlo, 0u));
   const u64 m = mad_op(0u - T0, p1, t1);
   u32 V2, w1, w2;
@@ -47,9 +32,35 @@ __device__ __forceinline__ u64 mont_diff_v3(u64 a, u64 b, const PrimeC &P) {
   const u32 ehi = __builtin_subc(V2, (u32)(n >> 32), w1, &w2);
   return mad_op(a1, b1, pair64(elo, ehi));
 }
+template <> __device__ __forceinline__ void bf<2>(u64 &X, u64 &Y, u64 W, const PrimeC &P) {
+  const u64 D = mont_diff_v2(W, Y, P);
+  const u64 xp = (X >= P.twop) ? X - P.p : X + P.p;
+  X = xp + D;
+  Y = xp - D;
+}
+// variant 3 = variant 1 with the high word brought down by a multiply-add by 1 instead of a 64-bit shift
+__device__ __forceinline__ u64 mad_one(u32 a, u64 c) {
+  u64 d, cc;
+  asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(d), "=s"(cc) : "v"(a), "v"(c));
+  return d;
+}
+__device__ __forceinline__ u64 mont_diff_v3(u64 a, u64 b, const PrimeC &P) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  const u32 p1 = P.p1;
+  const u64 t0 = mad_op_k(a0, b0);
+  const u64 t1 = mad_one((u32)(t0 >> 32), mad_op0(a1, b0));
+  const u64 m = mad_op(~(u32)t0, p1, t1);
+  u32 V2, w1, w2;
+  const u64 t2 = mad_op_carry(a0, b1, m, V2);
+  const u32 V0 = (u32)t2, V1 = (u32)(t2 >> 32);
+  const u64 n = mad_op0(V0, p1);
+  const u32 elo = __builtin_subc(V1, (u32)n, 0u, &w1);
+  const u32 ehi = __builtin_subc(V2, (u32)(n >> 32), w1, &w2);
+  return mad_op(a1, b1, pair64(elo, ehi));
+}
 template <> __device__ __forceinline__ void bf<3>(u64 &X, u64 &Y, u64 W, const PrimeC &P) {
   const u64 D = mont_diff_v3(W, Y, P);
-  const u64 xp = xp_fast(X, P);
+  const u64 xp = (X >= P.twop) ? X - P.p : X + P.p;
   X = xp + D;
   Y = xp - D;
 }
