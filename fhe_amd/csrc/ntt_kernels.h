@@ -81,6 +81,28 @@ __device__ __forceinline__ void fwd_phase(u64 (&e)[1 << LK], const u64 *__restri
   }
 }
 
+// Twiddles of one register phase fetched ahead of time: w[(1 << q) - 1 + kk] = tw[(base << q) + kk].  The stand-alone
+// passes issue these loads together with the data loads at the top of the kernel, so that a wave waits for memory once
+// instead of once per phase (forward passes: 4-5 % faster; the same change made the inverse row pass slower and is not used there).
+template <int LK>
+__device__ __forceinline__ void load_tw(u64 (&w)[(1 << LK) - 1], const u64 *__restrict__ tw, u32 base) {
+#pragma unroll
+  for (int q = 0; q < LK; ++q)
+#pragma unroll
+    for (int kk = 0; kk < (1 << q); ++kk) w[(1 << q) - 1 + kk] = tw[(base << q) + kk];
+}
+template <bool SP, int LK>
+__device__ __forceinline__ void fwd_phase_w(u64 (&e)[1 << LK], const u64 (&w)[(1 << LK) - 1], const PrimeC &P) {
+#pragma unroll
+  for (int q = 0; q < LK; ++q) {
+    const int half = 1 << (LK - 1 - q);
+#pragma unroll
+    for (int kk = 0; kk < (1 << q); ++kk)
+#pragma unroll
+      for (int j = 0; j < half; ++j) ct_bfly<SP>(e[kk * 2 * half + j], e[kk * 2 * half + j + half], w[(1 << q) - 1 + kk], P);
+  }
+}
+
 template <bool SP, int LK>
 __device__ __forceinline__ void inv_phase(u64 (&e)[1 << LK], const u64 *__restrict__ tw, u32 base, const PrimeC &P) {
 #pragma unroll
@@ -240,19 +262,24 @@ __global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
   u64 *d = a.dst + (u64)b * a.dst_bstride + (u64)l * N + (u64)row * 256;
   u64 *L = lds + rloc * ROW8_LDS;
   const u32 baseA = (1u << a.logR) + row;
-  u64 e[8];
-  // phase A: spans 128, 64, 32; thread holds {t + 32k}
+  const u32 c = t >> 2, r = t & 3;
+  u64 e[8], wA[7], wB[7], wC0[3], wC1[3];
+  // phase A: spans 128, 64, 32; thread holds {t + 32k}.  All twiddles of the three phases are requested here, behind the data.
 #pragma unroll
   for (int k = 0; k < 8; ++k) e[k] = s[t + 32 * k];
-  fwd_phase<SP, 3>(e, tw, baseA, P);
+  load_tw<3>(wA, tw, baseA);
+  load_tw<3>(wB, tw, (baseA << 3) + c);
+  load_tw<2>(wC0, tw, (baseA << 6) + 2 * t);
+  load_tw<2>(wC1, tw, (baseA << 6) + 2 * t + 1);
+  __builtin_amdgcn_sched_barrier(0);
+  fwd_phase_w<SP, 3>(e, wA, P);
 #pragma unroll
   for (int k = 0; k < 8; ++k) L[k * 36 + t] = e[k];
   wave_lds_sync();
   // phase B: spans 16, 8, 4 inside 32-element chunks; thread (c = t >> 2, r = t & 3) holds {32c + r + 4k}
-  const u32 c = t >> 2, r = t & 3;
 #pragma unroll
   for (int k = 0; k < 8; ++k) e[k] = L[c * 36 + r + 4 * k];
-  fwd_phase<SP, 3>(e, tw, (baseA << 3) + c, P);
+  fwd_phase_w<SP, 3>(e, wB, P);
 #pragma unroll
   for (int k = 0; k < 8; ++k) L[c * 36 + r + 4 * k] = e[k];
   wave_lds_sync();
@@ -265,8 +292,8 @@ __global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
       e[k] = v.x; e[k + 1] = v.y;
     }
     u64 g0[4] = {e[0], e[1], e[2], e[3]}, g1[4] = {e[4], e[5], e[6], e[7]};
-    fwd_phase<SP, 2>(g0, tw, (baseA << 6) + 2 * t, P);
-    fwd_phase<SP, 2>(g1, tw, (baseA << 6) + 2 * t + 1, P);
+    fwd_phase_w<SP, 2>(g0, wC0, P);
+    fwd_phase_w<SP, 2>(g1, wC1, P);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { e[k] = g0[k]; e[4 + k] = g1[k]; }
 #pragma unroll
@@ -499,6 +526,12 @@ __global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs
   const u64 nscale = (INVERSE && a.inv_scale) ? a.inv_scale[m] : P.ninv_m;
 
   if constexpr (!INVERSE) {
+    // twiddles of the second register phase (per thread) requested up front, with the data loads of the first
+    u64 wB[16 >> LB][(1 << LB) - 1];
+    if constexpr (LA > 0) {
+#pragma unroll
+      for (int rep = 0; rep < (16 >> LB); ++rep) load_tw<LB>(wB[rep], tw, (1u << LA) + (tid + rep * T) / CT);
+    }
     if constexpr (LA > 0) {
       constexpr int G = R >> LA;  // row groups in phase A
 #pragma unroll
@@ -522,7 +555,8 @@ __global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs
         const u32 row = (u << LB) + k;
         e[k] = (LA > 0) ? lds[row * CS + c] : s[(u64)row * 256 + c];
       }
-      fwd_phase<SP, LB>(e, tw, (1u << LA) + u, P);
+      if constexpr (LA > 0) fwd_phase_w<SP, LB>(e, wB[rep], P);
+      else fwd_phase<SP, LB>(e, tw, (1u << LA) + u, P);
 #pragma unroll
       for (int k = 0; k < (1 << LB); ++k) d[(u64)((u << LB) + k) * 256 + c] = e[k];  // lazy [0,4p)
     }
