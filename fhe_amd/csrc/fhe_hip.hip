@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 typedef unsigned __int128 u128;
@@ -960,6 +961,47 @@ int fhe_hip_rotate(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, s
 }
 int fhe_hip_rotate_non_ntt(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind) {
   return rotate_api(c, galois, ct, Li, batch, mem_kind, true);
+}
+
+// Single-process multi-GPU mode: contiguous split of the batch over the contexts, one host thread per context, each slice
+// in chunks through the ordinary host-pointer entry points (which stage through that context's device buffers).
+int fhe_hip_batch_run(fhe_hip_ctx *const *ctxs, uint32_t n_ctx, int op, uint64_t *out, const uint64_t *in0, const uint64_t *in1,
+                      uint64_t galois, uint32_t Li, size_t batch, int mem_kind) {
+  if (!ctxs || n_ctx == 0) return FHE_HIP_ERR_ARG;
+  for (u32 g = 0; g < n_ctx; ++g) if (!ctxs[g]) return FHE_HIP_ERR_ARG;
+  fhe_hip_ctx *c0 = ctxs[0];
+  if (mem_kind != FHE_HIP_MEM_HOST) FAIL(c0, FHE_HIP_ERR_ARG, "fhe_hip_batch_run takes host pointers only");
+  if (op != FHE_HIP_OP_MUL_RELIN_RESCALE && op != FHE_HIP_OP_ROTATE && op != FHE_HIP_OP_ROTATE_MIXED) FAIL(c0, FHE_HIP_ERR_ARG, "unknown op");
+  if (!out || (op == FHE_HIP_OP_MUL_RELIN_RESCALE && (!in0 || !in1))) FAIL(c0, FHE_HIP_ERR_ARG, "null argument");
+  for (u32 g = 1; g < n_ctx; ++g)
+    if (ctxs[g]->logN != c0->logN || ctxs[g]->L != c0->L || ctxs[g]->K != c0->K) FAIL(c0, FHE_HIP_ERR_ARG, "contexts of one set must share (logN, L, K)");
+  for (u32 g = 0; g < n_ctx; ++g)
+    for (u32 h = g + 1; h < n_ctx; ++h)
+      if (ctxs[g] == ctxs[h]) FAIL(c0, FHE_HIP_ERR_ARG, "a context may appear once in a set (a context is not thread-safe)");
+  TRY(check_li(c0, Li, 2));
+  if (batch == 0) return FHE_HIP_OK;
+  const u64 N = c0->N;
+  const size_t in_ct = (size_t)2 * Li * N, out_ct = (size_t)2 * (op == FHE_HIP_OP_MUL_RELIN_RESCALE ? Li - 1 : Li) * N;
+  constexpr size_t CHUNK = 32;
+  std::vector<int> rc(n_ctx, FHE_HIP_OK);
+  auto slice = [&](u32 g) {
+    const size_t lo = batch * g / n_ctx, hi = batch * (g + 1) / n_ctx;
+    for (size_t at = lo; at < hi && rc[g] == FHE_HIP_OK; at += CHUNK) {
+      const size_t n = std::min(CHUNK, hi - at);
+      if (op == FHE_HIP_OP_MUL_RELIN_RESCALE)
+        rc[g] = fhe_hip_mul_relin_rescale(ctxs[g], out + at * out_ct, in0 + at * in_ct, in1 + at * in_ct, Li, n, FHE_HIP_MEM_HOST);
+      else if (op == FHE_HIP_OP_ROTATE)
+        rc[g] = fhe_hip_rotate(ctxs[g], galois, out + at * out_ct, Li, n, FHE_HIP_MEM_HOST);
+      else
+        rc[g] = fhe_hip_rotate_mixed(ctxs[g], galois, out + at * out_ct, Li, n, FHE_HIP_MEM_HOST);
+    }
+  };
+  std::vector<std::thread> workers;
+  for (u32 g = 1; g < n_ctx; ++g) workers.emplace_back(slice, g);
+  slice(0);
+  for (auto &w : workers) w.join();
+  for (u32 g = 0; g < n_ctx; ++g) if (rc[g] != FHE_HIP_OK) return rc[g];
+  return FHE_HIP_OK;
 }
 
 int fhe_hip_load_mixed_rot_key(fhe_hip_ctx *c, uint64_t galois, const uint64_t *beta, const uint64_t *alpha, int mem_kind) {

@@ -81,6 +81,7 @@ def load_library():
         "fhe_hip_rotate_mixed": (i, [vp, u64, vp, u32, sz, i]),
         "fhe_hip_decrypt": (i, [vp, vp, vp, vp, u32, sz, i]),
         "fhe_hip_encrypt": (i, [vp, vp, vp, vp, vp, vp, vp, u32, sz, i]),
+        "fhe_hip_batch_run": (i, [C.POINTER(vp), u32, i, vp, vp, vp, u64, u32, sz, i]),
         "fhe_hip_profile_enable": (i, [vp, i]),
         "fhe_hip_profile_reset": (i, [vp]),
         "fhe_hip_profile_get": (i, [vp, C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double), i]),
@@ -98,8 +99,9 @@ EXPORTED_SYMBOLS = [
     "fhe_hip_mod_up", "fhe_hip_mod_down", "fhe_hip_rescale", "fhe_hip_load_mult_key", "fhe_hip_load_rot_key",
     "fhe_hip_add", "fhe_hip_multiply_plain", "fhe_hip_cross_mult", "fhe_hip_relin_only", "fhe_hip_relinearize",
     "fhe_hip_mul_relin_rescale", "fhe_hip_rotate", "fhe_hip_rotate_non_ntt", "fhe_hip_load_mixed_rot_key", "fhe_hip_rotate_mixed", "fhe_hip_decrypt", "fhe_hip_encrypt", "fhe_hip_profile_enable", "fhe_hip_profile_reset",
-    "fhe_hip_profile_get",
+    "fhe_hip_profile_get", "fhe_hip_batch_run",
 ]
+OP_MUL_RELIN_RESCALE, OP_ROTATE, OP_ROTATE_MIXED = 1, 2, 3
 
 
 def _buf(x):
@@ -290,3 +292,21 @@ class HipContext:
         if n < 0:
             self._chk(n)
         return {names[k].decode(): (int(launches[k]), float(ms[k])) for k in range(min(n, cap))}
+
+
+def batch_run(ctxs, op, out, in0=None, in1=None, galois=0, Li=0, batch=1):
+    """fhe_hip_batch_run: single-process multi-GPU mode (include/fhe_hip.h).  `ctxs` = HipContext objects, normally one per
+    GPU, each already holding the keys the op needs; the batch is split contiguously over them, one host thread per
+    context.  Host (numpy uint64) buffers only."""
+    ctxs = list(ctxs)
+    if not ctxs:
+        raise ValueError("batch_run needs at least one context")
+    bufs = [b for b in (out, in0, in1) if b is not None]
+    ptrs, kind = _same_kind(*bufs)
+    ptrs = list(ptrs) + [None] * (3 - len(ptrs))
+    handles = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    rc = ctxs[0].lib.fhe_hip_batch_run(handles, len(ctxs), op, ptrs[0], ptrs[1], ptrs[2], galois, Li, batch, kind)
+    if rc:
+        msgs = [c.lib.fhe_hip_last_error(c.h).decode() for c in ctxs]
+        raise FheHipError(rc, next((m for m in msgs if m), ""))
+    return out

@@ -124,6 +124,22 @@ int fhe_hip_decrypt(fhe_hip_ctx *ctx, uint64_t *out, const uint64_t *ct, const u
 int fhe_hip_encrypt(fhe_hip_ctx *ctx, uint64_t *ct, const uint64_t *u, const uint64_t *e0m, const uint64_t *e1,
                     const uint64_t *pk_b, const uint64_t *pk_a, uint32_t Li, size_t batch, int mem_kind);
 
+/* Single-process multi-GPU mode ("one ctx + stream set per device", batch index split contiguously:
+ * context g gets ops [g*B/G, (g+1)*B/G)).  No counterpart in the reference, which is single-threaded on one CPU; the
+ * sharding rule is the one of fhe_amd/batching.py (one process per GPU).  ctxs = n_ctx contexts, normally one per GPU,
+ * created with the same (logN, L, K, primes, psi) and each already holding the keys the op needs; every context runs its
+ * slice on a host thread of its own, in chunks of at most 32 ops staged through that context's device buffers (host
+ * pointers only: mem_kind must be FHE_HIP_MEM_HOST; device-resident callers drive the per-context entry points from their
+ * own threads).  Independent ciphertexts, no collective.  Returns the first non-zero status of any slice
+ * (fhe_hip_last_error(ctxs[g]) has the message).
+ *   FHE_HIP_OP_MUL_RELIN_RESCALE: out = [batch][2][Li-1][N], in0, in1 = [batch][2][Li][N]   (fhe_hip_mul_relin_rescale)
+ *   FHE_HIP_OP_ROTATE / _ROTATE_MIXED: out = [batch][2][Li][N] in place, in0 = in1 = NULL, galois  (fhe_hip_rotate[_mixed]) */
+#define FHE_HIP_OP_MUL_RELIN_RESCALE 1
+#define FHE_HIP_OP_ROTATE 2
+#define FHE_HIP_OP_ROTATE_MIXED 3
+int fhe_hip_batch_run(fhe_hip_ctx *const *ctxs, uint32_t n_ctx, int op, uint64_t *out, const uint64_t *in0, const uint64_t *in1,
+                      uint64_t galois, uint32_t Li, size_t batch, int mem_kind);
+
 /* Measurement support (no reference counterpart): when enabled every kernel launch is bracketed by
  * HIP events on the context's stream; stats are summed per kernel name. */
 int fhe_hip_profile_enable(fhe_hip_ctx *ctx, int on);

@@ -1,0 +1,99 @@
+"""GPU: fhe_hip_batch_run, the single-process multi-GPU mode: the batch is split contiguously over a
+set of contexts, one host thread each.  The box has one GPU, so the set is several contexts on device 0: same code path
+(threads, slices, chunks, staging), and the concatenated result must equal the CPU oracle's and a single context's."""
+import numpy as np
+import pytest
+
+import fhe_amd
+from fhe_amd import hip
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+LOGN, L, K = 10, 3, 2
+
+
+def _set(n):
+    pr, ps = orc.gen_primes(LOGN, L + K)
+    return orc.Oracle(LOGN, L, K, pr, ps), [fhe_amd.HipContext(LOGN, L, K, pr, ps) for _ in range(n)]
+
+
+def _rand(rng, primes, *shape):
+    """uniform residues, limb axis second to last, below the smallest prime"""
+    return rng.integers(0, int(min(primes)), size=shape, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("n_ctx,batch", [(2, 5), (3, 2), (2, 70), (1, 3)])
+def test_mul_relin_rescale_over_a_context_set(n_ctx, batch):
+    o, ctxs = _set(n_ctx)
+    rng = np.random.default_rng(100 + batch)
+    N, Li = o.N, L
+    beta, alpha = _rand(rng, o.primes, L, L, N), _rand(rng, o.primes, L, L, N)
+    for c in ctxs:
+        c.load_mult_key(beta, alpha)
+    c0, c1 = _rand(rng, o.primes, batch, 2, Li, N), _rand(rng, o.primes, batch, 2, Li, N)
+    out = np.zeros((batch, 2, Li - 1, N), dtype=np.uint64)
+    hip.batch_run(ctxs, hip.OP_MUL_RELIN_RESCALE, out, c0, c1, Li=Li, batch=batch)
+    single = np.zeros_like(out)
+    ctxs[0].mul_relin_rescale(single, c0, c1, Li, batch=batch)
+    assert np.array_equal(out, single)
+    for b in sorted({0, batch // 2, batch - 1}):  # slice boundaries included; every entry went through the same kernels
+        wb, wa = o.mul_relin_rescale(c0[b, 0], c0[b, 1], c1[b, 0], c1[b, 1], beta, alpha)
+        assert np.array_equal(out[b, 0], wb) and np.array_equal(out[b, 1], wa)
+
+
+def test_rotations_over_a_context_set():
+    o, ctxs = _set(2)
+    rng = np.random.default_rng(7)
+    N, Li, batch = o.N, L, 5
+    gal = o.rotation_galois(1)
+    rkb, rka = _rand(rng, o.primes, L + K, N), _rand(rng, o.primes, L + K, N)
+    xb, xa = _rand(rng, o.primes, L, L + 1, N), _rand(rng, o.primes, L, L + 1, N)
+    for c in ctxs:
+        c.load_rot_key(gal, rkb, rka)
+        c.load_mixed_rot_key(gal, xb, xa)
+    ct = _rand(rng, o.primes, batch, 2, Li, N)
+    work = ct.copy()
+    hip.batch_run(ctxs, hip.OP_ROTATE, work, galois=gal, Li=Li, batch=batch)
+    for b in range(batch):
+        wb, wa = o.rotate(ct[b, 0], ct[b, 1], gal, rkb, rka)
+        assert np.array_equal(work[b, 0], wb) and np.array_equal(work[b, 1], wa)
+    work = ct.copy()
+    hip.batch_run(ctxs, hip.OP_ROTATE_MIXED, work, galois=gal, Li=Li, batch=batch)
+    for b in range(batch):
+        wb, wa = o.rotate_mixed(ct[b, 0], ct[b, 1], gal, xb, xa)
+        assert np.array_equal(work[b, 0], wb) and np.array_equal(work[b, 1], wa)
+
+
+def test_batch_run_argument_errors():
+    o, ctxs = _set(2)
+    N, Li = o.N, L
+    out = np.zeros((2, 2, Li - 1, N), dtype=np.uint64)
+    c0 = np.zeros((2, 2, Li, N), dtype=np.uint64)
+    with pytest.raises(fhe_amd.FheHipError) as e:  # keys were never loaded: the slices report it
+        hip.batch_run(ctxs, hip.OP_MUL_RELIN_RESCALE, out, c0, c0, Li=Li, batch=2)
+    assert e.value.code == -3
+    with pytest.raises(fhe_amd.FheHipError) as e:  # a context twice in one set
+        hip.batch_run([ctxs[0], ctxs[0]], hip.OP_MUL_RELIN_RESCALE, out, c0, c0, Li=Li, batch=2)
+    assert e.value.code == -1
+    with pytest.raises(fhe_amd.FheHipError) as e:  # unknown op
+        hip.batch_run(ctxs, 99, out, c0, c0, Li=Li, batch=2)
+    assert e.value.code == -1
+    with pytest.raises(fhe_amd.FheHipError) as e:  # inputs missing
+        hip.batch_run(ctxs, hip.OP_MUL_RELIN_RESCALE, out, Li=Li, batch=2)
+    assert e.value.code == -1
+    with pytest.raises(fhe_amd.FheHipError) as e:  # Li out of range
+        hip.batch_run(ctxs, hip.OP_MUL_RELIN_RESCALE, out, c0, c0, Li=L + 1, batch=2)
+    assert e.value.code == -2
+    dev = torch.zeros((2, 2, Li, N), dtype=torch.int64, device="cuda")
+    dout = torch.zeros((2, 2, Li - 1, N), dtype=torch.int64, device="cuda")
+    with pytest.raises(fhe_amd.FheHipError) as e:  # device pointers: one slice per device needs per-device buffers
+        hip.batch_run(ctxs, hip.OP_MUL_RELIN_RESCALE, dout, dev, dev, Li=Li, batch=2)
+    assert e.value.code == -1
+    pr, ps = orc.gen_primes(LOGN + 1, L + K)
+    other = fhe_amd.HipContext(LOGN + 1, L, K, pr, ps)
+    with pytest.raises(fhe_amd.FheHipError) as e:  # contexts of different rings
+        hip.batch_run([ctxs[0], other], hip.OP_MUL_RELIN_RESCALE, out, c0, c0, Li=Li, batch=2)
+    assert e.value.code == -1
+    hip.batch_run(ctxs, hip.OP_MUL_RELIN_RESCALE, out, c0, c0, Li=Li, batch=0)  # empty batch: no-op
