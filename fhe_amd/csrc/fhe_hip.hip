@@ -805,6 +805,20 @@ int fhe_hip_mod_down(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t
   return st.finish();
 }
 
+int fhe_hip_conv_to_normal(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *sp, uint32_t L0, size_t batch, int mem_kind) {
+  TRY(check_ctx(c));
+  if (!rop || !sp) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (L0 < 1 || L0 > c->L) FAIL(c, FHE_HIP_ERR_RANGE, "target limb count out of range");
+  if (c->K < 1) FAIL(c, FHE_HIP_ERR_RANGE, "conversion from the special basis needs special primes");
+  if (batch == 0) return FHE_HIP_OK;
+  Staged st(c, mem_kind);
+  const u64 *dsp = nullptr; u64 *drop = nullptr;
+  TRY(st.in(sp, batch * c->K * c->N * 8, &dsp));
+  TRY(st.out(rop, batch * L0 * c->N * 8, &drop, false));
+  TRY(dev_conv_to_normal(c, drop, L0, dsp, c->K, 0, (u32)batch));
+  return st.finish();
+}
+
 int fhe_hip_rescale(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t n, size_t batch, int mem_kind) {
   TRY(check_ctx(c));
   if (!rop || !op) FAIL(c, FHE_HIP_ERR_ARG, "null argument");

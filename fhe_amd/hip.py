@@ -67,6 +67,7 @@ def load_library():
         "fhe_hip_mod_up": (i, [vp, vp, vp, u32, sz, i]),
         "fhe_hip_mod_down": (i, [vp, vp, vp, u32, sz, i]),
         "fhe_hip_rescale": (i, [vp, vp, vp, u32, sz, i]),
+        "fhe_hip_conv_to_normal": (i, [vp, vp, vp, u32, sz, i]),
         "fhe_hip_load_mult_key": (i, [vp, vp, vp, i]),
         "fhe_hip_load_rot_key": (i, [vp, u64, vp, vp, i]),
         "fhe_hip_add": (i, [vp, vp, vp, u32, sz, i]),
@@ -99,7 +100,7 @@ EXPORTED_SYMBOLS = [
     "fhe_hip_mod_up", "fhe_hip_mod_down", "fhe_hip_rescale", "fhe_hip_load_mult_key", "fhe_hip_load_rot_key",
     "fhe_hip_add", "fhe_hip_multiply_plain", "fhe_hip_cross_mult", "fhe_hip_relin_only", "fhe_hip_relinearize",
     "fhe_hip_mul_relin_rescale", "fhe_hip_rotate", "fhe_hip_rotate_non_ntt", "fhe_hip_load_mixed_rot_key", "fhe_hip_rotate_mixed", "fhe_hip_decrypt", "fhe_hip_encrypt", "fhe_hip_profile_enable", "fhe_hip_profile_reset",
-    "fhe_hip_profile_get", "fhe_hip_batch_run",
+    "fhe_hip_profile_get", "fhe_hip_batch_run", "fhe_hip_conv_to_normal",
 ]
 OP_MUL_RELIN_RESCALE, OP_ROTATE, OP_ROTATE_MIXED = 1, 2, 3
 
@@ -202,6 +203,13 @@ class HipContext:
     def rescale(self, rop, op, n, batch=1):
         (r, o), kind = _same_kind(rop, op)
         self._chk(self.lib.fhe_hip_rescale(self.h, r, o, n, batch, kind))
+        return rop
+
+    def conv_to_normal(self, rop, sp, L0, batch=1):
+        """BaseConverter::neg_approx_convert_to_normal_basis for targets 0..L0-1 (src/base_converter.cpp:297-311):
+        sp = [batch][K][N] special limbs, power basis -> rop = [batch][L0][N], power basis."""
+        (r, o), kind = _same_kind(rop, sp)
+        self._chk(self.lib.fhe_hip_conv_to_normal(self.h, r, o, L0, batch, kind))
         return rop
 
     # ---- keys -------------------------------------------------------------------------------

@@ -37,5 +37,13 @@ struct BaseConverter {
     if (!approximated_mod_up(&ext, op)) return;
     std::memcpy(rop, ext.cptr_at(op.moduli_count() + sp_moduli_index), sizeof(T) * context::degree);
   }
+  // op = the K special limbs in the power basis -> -conv_{P -> q_j}(op) for one normal modulus j (:297-311)
+  void neg_approx_convert_to_normal_basis(T *rop, context::poly_t const &op, const size_t nrl_moduli_index) const {
+    if (!rop) return;
+    if (op.moduli_count() != context::nr_sp_primes || nrl_moduli_index >= context::nr_ctxt_moduli) throw std::invalid_argument("neg_approx_convert_to_normal_basis: shape");
+    context::poly_t conv(nrl_moduli_index + 1);
+    yell::check(fhe_hip_conv_to_normal(yell::runtime::get().ctx, conv.ptr_at(0), op.cptr_at(0), (uint32_t)(nrl_moduli_index + 1), 1, FHE_HIP_MEM_HOST), "conv_to_normal");
+    std::memcpy(rop, conv.cptr_at(nrl_moduli_index), sizeof(T) * context::degree);
+  }
 };
 }  // namespace fHE

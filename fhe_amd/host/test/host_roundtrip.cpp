@@ -148,6 +148,27 @@ int main(int argc, char **argv) {
       }
     }
 
+    // BaseConverter mirror (base_converter.hpp:18-35): mod_up, the two single-target conversions, mod_down, rescale
+    fHE::BaseConverter bconv;
+    fHE::context::poly_t bc_in(in_a.ax);
+    bc_in.backward();  // power basis
+    fHE::context::poly_t bc_up(L + K), bc_down(L), bc_resc(L - 1), bc_sp(K), bc_one(2);
+    if (!bconv.approximated_mod_up(&bc_up, bc_in)) { std::fprintf(stderr, "approximated_mod_up failed\n"); return 23; }
+    std::vector<T> single(N);
+    bconv.approx_convert_to_special_basis(single.data(), bc_in, K - 1);
+    if (std::memcmp(single.data(), bc_up.cptr_at(L + K - 1), N * 8)) { std::fprintf(stderr, "approx_convert_to_special_basis differs from mod_up\n"); return 24; }
+    std::memcpy(bc_sp.ptr_at(0), bc_up.cptr_at(L), K * N * 8);
+    std::memcpy(bc_one.ptr_at(0), single.data(), N * 8);  // reuse as scratch for the second single-target call
+    bconv.neg_approx_convert_to_normal_basis(bc_one.ptr_at(1), bc_sp, L - 1);
+    fHE::context::poly_t bc_mixed(bc_up);  // normal limbs to the NTT basis, special limbs stay in the power basis (:205-209)
+    for (size_t j = 0; j < L; ++j) yell::ntt::forward(bc_mixed.ptr_at(j), j);
+    if (!bconv.approximated_mod_down(&bc_down, bc_mixed)) { std::fprintf(stderr, "approximated_mod_down failed\n"); return 25; }
+    fHE::context::poly_t bc_r_in(in_a.ax);
+    yell::ntt::backward(bc_r_in.ptr_at(L - 1), L - 1);  // last limb in the power basis (:246)
+    if (!bconv.rescale(&bc_resc, bc_r_in)) { std::fprintf(stderr, "rescale failed\n"); return 26; }
+    try { fHE::context::poly_t one(1), ext(1 + K); bconv.approximated_mod_up(&ext, one); std::fprintf(stderr, "mod_up accepted one limb\n"); return 27; }
+    catch (std::invalid_argument const &) {}
+
     FILE *f = std::fopen(path, "wb");
     if (!f) { std::perror("fopen"); return 9; }
     uint64_t hdr[4] = {logN, L, K, rkey.galois};
@@ -166,6 +187,8 @@ int main(int argc, char **argv) {
     dump(f, "nn5_bx", nn5.bx); dump(f, "nn5_ax", nn5.ax);
     for (size_t i = 0; i + 1 < logN; ++i) { auto k = rset.get((uint16_t)(1u << i)); dump(f, "rs_beta", k->beta); dump(f, "rs_alpha", k->alpha); }
     dump(f, "rep_mask", rep_mask); dump(f, "rep_bx", rep.bx); dump(f, "rep_ax", rep.ax);
+    dump(f, "bc_in", bc_in); dump(f, "bc_up", bc_up); dump(f, "bc_mixed", bc_mixed); dump(f, "bc_down", bc_down);
+    dump(f, "bc_r_in", bc_r_in); dump(f, "bc_resc", bc_resc); dump(f, "bc_one", bc_one);
     std::fclose(f);
     // the multiplied ciphertext and the rotation key once more in the limb-dump wire format (fHE/wire.hpp), read back here
     {

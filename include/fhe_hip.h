@@ -74,6 +74,12 @@ int fhe_hip_mod_down(fhe_hip_ctx *ctx, uint64_t *rop, const uint64_t *op, uint32
 /* BaseConverter::rescale (:244-274): op [batch][n][N] (last limb power basis, rest NTT basis) ->
  * rop [batch][n-1][N] NTT basis; floor-style, no rounding term. */
 int fhe_hip_rescale(fhe_hip_ctx *ctx, uint64_t *rop, const uint64_t *op, uint32_t n, size_t batch, int mem_kind);
+/* BaseConverter::neg_approx_convert_to_normal_basis for the targets j = 0..L0-1 (src/base_converter.cpp:297-311 over
+ * :313-349): sp = [batch][K][N], the K special limbs in the power basis -> rop = [batch][L0][N] with
+ * rop_j = sum_k [sp_k * hat_pi_invmod_pi_k]_{p_k} * neg_hat_pi_mod_qj[j][k] mod q_j, power basis (the conversion inside
+ * approximated_mod_down before its NTT, :220-223).  approx_convert_to_special_basis (:276-295) is the special-limb part
+ * of fhe_hip_mod_up. */
+int fhe_hip_conv_to_normal(fhe_hip_ctx *ctx, uint64_t *rop, const uint64_t *sp, uint32_t L0, size_t batch, int mem_kind);
 
 /* MultKey (include/fHE/mult_key.hpp:5-38): beta/alpha = [L][L][N] (key j, limb i), NTT basis.
  * RotKey (include/fHE/rot_key.hpp:9-39): beta/alpha = [L+K][N], NTT basis, selected later by galois.

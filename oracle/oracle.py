@@ -41,6 +41,8 @@ def _load():
         "orc_rotation_galois": (u64, [vp, i, i]),
         "orc_approx_convert_to_special_basis": (None, [vp, u64p, u64p, u32, u32]),
         "orc_neg_approx_convert_to_normal_basis": (None, [vp, u64p, u64p, u32]),
+        "orc_approx_convert_to_special_basis": (None, [vp, u64p, u64p, u32, u32]),
+        "orc_neg_approx_convert_to_normal_basis": (None, [vp, u64p, u64p, u32]),
         "orc_mod_up": (i, [vp, u64p, u64p, u32]),
         "orc_mod_down": (i, [vp, u64p, u64p, u32]),
         "orc_rescale": (i, [vp, u64p, u64p, u32]),
@@ -138,6 +140,16 @@ class Oracle:
         n = C.c_size_t(0)
         ptr = lib.orc_bconv_table(self.h, which, C.byref(n))
         return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint64)
+
+    def approx_convert_to_special_basis(self, op, k):  # base_converter.cpp:276-295
+        rop = np.zeros(self.N, np.uint64)
+        lib.orc_approx_convert_to_special_basis(self.h, _p(rop), _p(op), op.shape[0], k)
+        return rop
+
+    def neg_approx_convert_to_normal_basis(self, sp, j):  # base_converter.cpp:297-311; sp = [K][N] power basis
+        rop = np.zeros(self.N, np.uint64)
+        lib.orc_neg_approx_convert_to_normal_basis(self.h, _p(rop), _p(sp), j)
+        return rop
 
     def mod_up(self, op):
         Li = op.shape[0]

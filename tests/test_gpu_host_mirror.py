@@ -92,6 +92,13 @@ def test_config1_roundtrip_through_cpp_api(tmp_path, logN, L, K):
         want3 = o.apply_galois_non_ntt(d["msg_a"][0].copy(), o.rotation_galois(3))[0]
         d3 = (d["dec_rot3"][0][0].astype(object) - want3.astype(object)) % p0
         assert int(np.minimum(d3, p0 - d3).max()) < 1 << 30
+    # BaseConverter through the C++ API (base_converter.hpp:18-35)
+    assert np.array_equal(d["bc_in"][0], o.ntt_backward(a_ax.copy(), range(L)))
+    assert np.array_equal(d["bc_up"][0], o.mod_up(d["bc_in"][0]))
+    assert np.array_equal(d["bc_down"][0], o.mod_down(d["bc_mixed"][0]))
+    assert np.array_equal(d["bc_resc"][0], o.rescale(d["bc_r_in"][0]))
+    assert np.array_equal(d["bc_one"][0][0], o.approx_convert_to_special_basis(d["bc_in"][0], K - 1))
+    assert np.array_equal(d["bc_one"][0][1], o.neg_approx_convert_to_normal_basis(np.ascontiguousarray(d["bc_up"][0][L:]), L - 1))
     # ---- SURVEY 8(f) rank 2 / rank 4 through the C++ API: Encoder, rotate_slots_non_ntt, replicate ----
     enc = EncoderOracle(logN)
     slots = N >> 1

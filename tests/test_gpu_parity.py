@@ -220,6 +220,21 @@ def test_mod_up_mod_down_rescale(logN, L, K, Li, sp):
     rop = torch.zeros((2, Li - 1, o.N), dtype=torch.int64, device="cuda")
     g.rescale(rop, dev(x), Li, batch=2)
     assert np.array_equal(host(rop), want)
+    # the single-target conversions behind them (BaseConverter::approx_convert_to_special_basis /
+    # neg_approx_convert_to_normal_basis, base_converter.cpp:276-311)
+    up = host(g.mod_up(torch.zeros((2, Li + K, o.N), dtype=torch.int64, device="cuda"), dev(x), Li, batch=2))
+    for k in range(K):
+        assert np.array_equal(up[1, Li + k], o.approx_convert_to_special_basis(x[1], k))
+    sp_part = np.ascontiguousarray(y[:, Li:])
+    for L0 in sorted({1, Li, L}):
+        rop = torch.zeros((2, L0, o.N), dtype=torch.int64, device="cuda")
+        g.conv_to_normal(rop, dev(sp_part), L0, batch=2)
+        for b in range(2):
+            for j in range(L0):
+                assert np.array_equal(host(rop)[b, j], o.neg_approx_convert_to_normal_basis(sp_part[b], j))
+    with pytest.raises(fhe_amd.FheHipError) as ei:
+        g.conv_to_normal(torch.zeros((1, L + 1, o.N), dtype=torch.int64, device="cuda"), dev(sp_part[:1]), L + 1)
+    assert ei.value.code == -2
 
 
 def test_mod_up_rejects_single_limb_like_reference():
