@@ -88,9 +88,8 @@ __global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
 #pragma unroll
     for (int w = 0; w < 6; ++w) acc[t][w] = 0;
   }
-  for (u32 k = 0; k < a.nsrc; ++k) {
+  auto term = [&](u32 k, u64 xk) {
     [[maybe_unused]] const PrimeC PS = a.primes[a.src_first + k];
-    const u64 xk = sp[(u64)k * a.N];
     u64 t0;  // canonical digit [x_k * inv_k] mod the source prime
     if constexpr (PRE) t0 = xk; else t0 = csub(mont_mul<SP>(a.inv_m[k], xk, PS), PS.p);
     const u32 b0 = (u32)t0, b1 = (u32)(t0 >> 32);
@@ -105,7 +104,21 @@ __global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
       acc[t][4] = mad_wide(h1, b1, acc[t][4]);
       acc[t][5] = mad_wide(h2, b1, acc[t][5]);
     }
+  };
+  // source limbs are requested one term ahead, ping-pong between two registers (no copy, so no wait at the loop end);
+  // indices are clamped instead of branching, the odd last term is peeled
+  const u32 last = a.nsrc - 1;
+  u64 xa = sp[0], xb;
+  u32 k = 0;
+  for (; k + 1 < a.nsrc; k += 2) {
+    xb = sp[(u64)(k + 1) * a.N];
+    __builtin_amdgcn_sched_barrier(0);
+    term(k, xa);
+    xa = sp[(u64)(k + 2 < last ? k + 2 : last) * a.N];
+    __builtin_amdgcn_sched_barrier(0);
+    term(k + 1, xb);
   }
+  if (k < a.nsrc) term(k, xa);
 #pragma unroll
   for (int t = 0; t < BCONV_TC; ++t) {
     const u32 m = a.tgt_first + tt[t];
