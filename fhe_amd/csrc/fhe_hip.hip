@@ -50,13 +50,12 @@ struct fhe_hip_ctx {
   u32 *d_iota = nullptr;                         // [M] identity modulus map
   u32 *d_rotmap = nullptr;                       // [L+1][M]: row Li: cm < Li ? cm : L + cm - Li
   u64 *d_hat_pi_inv_m = nullptr;                 // [K]          mod p_k
-  u64 *d_neg_hat_pi_qj_m = nullptr;              // [L][K]       mod q_l
+  u64 *d_neg_hat_pi_qj_m = nullptr;              // [L][K]       mod q_l, times 2^128 (bconv_fold)
   u64 *d_Pinv_qj_m = nullptr;                    // [L]          mod q_j
   u64 *d_modup_scale_m = nullptr;                // [L-1][M]   N^-1 * hat_qj_inv[Li-2][j] mod q_j (row Li-2), Montgomery form
   u64 *d_moddown_scale_m = nullptr;              // [M]        N^-1 * hat_pi_inv[k] mod p_k at index L+k, Montgomery form
-  u64 *d_pow2w = nullptr;                        // [M][6]       2^w mod p, w = 0,21,42,32,53,74 (bconv fold)
   u64 *d_hat_qj_inv_m = nullptr;                 // [L-1][L]     mod q_j
-  u64 *d_hat_qj_pi_m = nullptr;                  // [L-1][K][L]  mod p_k
+  u64 *d_hat_qj_pi_m = nullptr;                  // [L-1][K][L]  mod p_k, times 2^128
   u64 *d_qinv_m = nullptr;                       // [M][M]: (P[a]^-1 mod P[j]) Montgomery, row a
   // keys
   u64 *d_mk_beta = nullptr, *d_mk_alpha = nullptr;  // [L][L][N] Montgomery form
@@ -322,7 +321,7 @@ int dev_conv_to_special(fhe_hip_ctx *c, u64 *rop, u32 rop_limbs, u32 rop_off, co
   a.out = rop; a.src = op;
   a.inv_m = c->d_hat_qj_inv_m + (size_t)(Li - 2) * c->L;
   a.hat_m = c->d_hat_qj_pi_m + (size_t)(Li - 2) * c->K * c->L;
-  a.primes = c->d_primes; a.pow2w = c->d_pow2w;
+  a.primes = c->d_primes;
   a.nsrc = Li; a.src_first = 0; a.src_limbs = op_limbs; a.src_off = 0;
   a.tgt_first = c->L; a.out_limbs = rop_limbs; a.out_off = rop_off; a.hat_stride = c->L; a.ntgt = c->K;
   a.N = c->N;
@@ -338,7 +337,7 @@ int dev_conv_to_normal(fhe_hip_ctx *c, u64 *rop, u32 L0, const u64 *op, u32 op_l
   a.out = rop; a.src = op;
   a.inv_m = c->d_hat_pi_inv_m;
   a.hat_m = c->d_neg_hat_pi_qj_m;
-  a.primes = c->d_primes; a.pow2w = c->d_pow2w;
+  a.primes = c->d_primes;
   a.nsrc = c->K; a.src_first = c->L; a.src_limbs = op_limbs; a.src_off = sp_off;
   a.tgt_first = 0; a.out_limbs = L0; a.out_off = 0; a.hat_stride = c->K; a.ntgt = L0;
   a.N = c->N;
@@ -676,13 +675,13 @@ int fhe_hip_ctx_create(fhe_hip_ctx **out, uint32_t logN, uint32_t L, uint32_t K,
   for (uint32_t k = 0; k < K; ++k) {
     const uint32_t cm = L + k;
     hat_pi_inv[k] = h_to_mont(h_invmod(h_product_of(P, L, K, (int)k, cm), P[cm]), P[cm]);
-    for (uint32_t l = 0; l < L; ++l) neg_hat[(size_t)l * K + k] = h_to_mont(P[l] - h_product_of(P, L, K, (int)k, l), P[l]);
+    for (uint32_t l = 0; l < L; ++l) neg_hat[(size_t)l * K + k] = h_to_mont(h_to_mont(P[l] - h_product_of(P, L, K, (int)k, l), P[l]), P[l]);  // x 2^128: bconv_fold
   }
   for (uint32_t n = 2; n <= L; ++n) {
     const uint32_t l = n - 2;
     for (uint32_t j = 0; j < n; ++j) hat_qj_inv[(size_t)l * L + j] = h_to_mont(h_invmod(h_product_of(P, 0, n, (int)j, j), P[j]), P[j]);
     for (uint32_t k = 0; k < K; ++k)
-      for (uint32_t j = 0; j < n; ++j) hat_qj_pi[((size_t)l * K + k) * L + j] = h_to_mont(h_product_of(P, 0, n, (int)j, L + k), P[L + k]);
+      for (uint32_t j = 0; j < n; ++j) hat_qj_pi[((size_t)l * K + k) * L + j] = h_to_mont(h_to_mont(h_product_of(P, 0, n, (int)j, L + k), P[L + k]), P[L + k]);
   }
   for (uint32_t j = 0; j < L; ++j) Pinv[j] = h_to_mont(h_invmod(h_product_of(P, L, K, -1, j), P[j]), P[j]);
   for (uint32_t a = 0; a < M; ++a)
@@ -696,10 +695,6 @@ int fhe_hip_ctx_create(fhe_hip_ctx **out, uint32_t logN, uint32_t L, uint32_t K,
   for (uint32_t k = 0; k < K; ++k)
     moddown_scale[L + k] = h_to_mont(h_mulmod(h_invmod(N % P[L + k], P[L + k]), h_invmod(h_product_of(P, L, K, (int)k, L + k), P[L + k]), P[L + k]), P[L + k]);
   if ((rc = upload(c, &c->d_modup_scale_m, modup_scale)) || (rc = upload(c, &c->d_moddown_scale_m, moddown_scale))) return fail(rc);
-  std::vector<u64> pow2w((size_t)M * 6);
-  for (uint32_t m = 0; m < M; ++m)
-    for (int w = 0; w < 6; ++w) pow2w[(size_t)m * 6 + w] = h_powmod(2, (u64)kBconvWeights[w], P[m]);
-  if ((rc = upload(c, &c->d_pow2w, pow2w))) return fail(rc);
   if ((rc = upload(c, &c->d_hat_pi_inv_m, hat_pi_inv)) || (rc = upload(c, &c->d_neg_hat_pi_qj_m, neg_hat)) || (rc = upload(c, &c->d_Pinv_qj_m, Pinv)) ||
       (rc = upload(c, &c->d_hat_qj_inv_m, hat_qj_inv)) || (rc = upload(c, &c->d_hat_qj_pi_m, hat_qj_pi)) || (rc = upload(c, &c->d_qinv_m, qinv)))
     return fail(rc);
@@ -713,7 +708,7 @@ void fhe_hip_ctx_destroy(fhe_hip_ctx *c) {
   hipDeviceSynchronize();
   prof_drain(c);
   void *ptrs[] = {c->d_primes, c->d_tw_fwd, c->d_tw_inv, c->d_iota, c->d_rotmap, c->d_hat_pi_inv_m, c->d_neg_hat_pi_qj_m, c->d_Pinv_qj_m,
-                  c->d_hat_qj_inv_m, c->d_hat_qj_pi_m, c->d_qinv_m, c->d_mk_beta, c->d_mk_alpha, c->d_pow2w, c->d_modup_scale_m, c->d_moddown_scale_m};
+                  c->d_hat_qj_inv_m, c->d_hat_qj_pi_m, c->d_qinv_m, c->d_mk_beta, c->d_mk_alpha, c->d_modup_scale_m, c->d_moddown_scale_m};
   for (void *p : ptrs) if (p) hipFree(p);
   for (auto &kv : c->rot_keys) { hipFree(kv.second.beta_m); hipFree(kv.second.alpha_m); }
   for (auto &kv : c->mixed_keys) { hipFree(kv.second.beta_m); hipFree(kv.second.alpha_m); }

@@ -59,8 +59,7 @@ __global__ __launch_bounds__(PW_THREADS) void rescale_kernel(u64 *out, const u64
 struct BconvArgs {
   u64 *out; const u64 *src;
   const u64 *inv_m;   // [nsrc]  Montgomery form w.r.t. the source prime
-  const u64 *hat_m;   // [ntgt][hat_stride]  Montgomery form w.r.t. the target prime
-  const u64 *pow2w;   // [M][6]  2^w mod p for the accumulator weights w = 0, 21, 42, 32, 53, 74 (plain residues)
+  const u64 *hat_m;   // [ntgt][hat_stride]  times 2^128 mod the target prime (two Montgomery factors: see bconv_fold)
   const PrimeC *primes;
   u32 nsrc, src_first, src_limbs, src_off;
   u32 tgt_first, out_limbs, out_off, hat_stride, ntgt;
@@ -70,10 +69,26 @@ struct BconvArgs {
 // is computed once.  Every VALU instruction costs one issue slot on gfx950, so the sum
 // sum_k hat[t][k] * t0_k is accumulated WITHOUT carries: hat (< 2^62, uniform, split by the scalar unit into three
 // 21-bit limbs) times t0 (two 32-bit words) gives six partial products < 2^53, each added into its own 64-bit
-// accumulator by one v_mad_u64_u32 (room for 2^10 terms).  The six accumulators are folded once per target at the end:
-// hat is in Montgomery form, so mont(2^w mod p, acc_w) = acc_w' * 2^w mod p of the plain sum.
+// accumulator by one v_mad_u64_u32 (room for 2^8 terms).  The six accumulators are folded once per target at the end
+// (bconv_fold).
 #define BCONV_TC 5
-__device__ constexpr int kBconvWeights[6] = {0, 21, 42, 32, 53, 74};
+// Fold of the six carry-free accumulators A_w (weights 2^w, w = 0, 21, 42 | 32, 53, 74; each < 2^61): the weighted sum
+// T = sum_w A_w 2^w = sum_k hat_k * t0_k (< 2^134) is put together with integer shifts and adds, then taken through two
+// 64-bit Montgomery reductions, T * 2^-128 mod p.  The hat tables are stored times 2^128 mod p, so this is the plain
+// residue.  2 x (2 multiply-adds + 6) + ~30 word operations per target instead of six Montgomery multiplications.
+template <bool SP>
+__device__ __forceinline__ u64 bconv_fold(const u64 (&A)[6], const PrimeC &PT) {
+  typedef unsigned __int128 u128;
+  const u128 U = (u128)A[0] + ((u128)A[1] << 21) + ((u128)A[2] << 42);  // < 2^104
+  const u128 V = (u128)A[3] + ((u128)A[4] << 21) + ((u128)A[5] << 42);  // < 2^104, weight 2^32
+  const u128 S = U + (V << 32);                                         // T mod 2^128
+  const u64 X0 = (u64)S, X1 = (u64)(S >> 64);
+  const u64 X2 = (u64)(V >> 96) + (S < U ? 1u : 0u);                    // T >> 128, < 2^9
+  const u64 r1 = mont_reduce<SP>(0, X0, PT);                            // X0 * 2^-64 (mod p), in (0, p]
+  const u64 w_lo = X1 + r1;
+  const u64 w_hi = X2 + (w_lo < r1 ? 1u : 0u);                          // (w_hi : w_lo) = (T + m*p) / 2^64 < 2^71
+  return csub(mont_reduce<SP>(w_hi, w_lo, PT), PT.p);                   // (0, p + w_hi] -> [0, p)
+}
 template <bool SP, bool PRE = false>
 __global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
   const u64 d = (u64)blockIdx.x * PW_THREADS + threadIdx.x;
@@ -121,12 +136,9 @@ __global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
   if (k < a.nsrc) term(k, xa);
 #pragma unroll
   for (int t = 0; t < BCONV_TC; ++t) {
-    const u32 m = a.tgt_first + tt[t];
-    const PrimeC PT = a.primes[m];
-    u64 s = 0;  // lazy in [0, 2p)
-#pragma unroll
-    for (int w = 0; w < 6; ++w) s = csub(s + mont_mul<SP>(a.pow2w[(u64)m * 6 + w], acc[t][w], PT), PT.twop);
-    if (tbase + t < ntgt) a.out[((u64)e * a.out_limbs + a.out_off + tbase + t) * a.N + d] = csub(s, PT.p);
+    const PrimeC PT = a.primes[a.tgt_first + tt[t]];
+    const u64 r = bconv_fold<SP>(acc[t], PT);
+    if (tbase + t < ntgt) a.out[((u64)e * a.out_limbs + a.out_off + tbase + t) * a.N + d] = r;
   }
 }
 
