@@ -16,6 +16,8 @@
 typedef unsigned __int128 u128;
 
 static thread_local std::string g_create_error;
+// no exception crosses the C ABI (std::bad_alloc from the host-side containers is the only realistic one)
+static int abi_exception() { try { g_create_error = "C++ exception inside the library (out of host memory?)"; } catch (...) {} return FHE_HIP_ERR_HIP; }
 
 namespace {
 
@@ -619,6 +621,7 @@ extern "C" {
 const char *fhe_hip_last_error(const fhe_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int fhe_hip_ctx_create(fhe_hip_ctx **out, uint32_t logN, uint32_t L, uint32_t K, const uint64_t *primes, const uint64_t *psi, int device) {
+  try {
   if (!out || !primes || !psi) { g_create_error = "null argument"; return FHE_HIP_ERR_ARG; }
   *out = nullptr;
   if (logN < 10 || logN > 16) { g_create_error = "logN must be in [10, 16]"; return FHE_HIP_ERR_RANGE; }
@@ -700,6 +703,7 @@ int fhe_hip_ctx_create(fhe_hip_ctx **out, uint32_t logN, uint32_t L, uint32_t K,
     return fail(rc);
   *out = c;
   return FHE_HIP_OK;
+  } catch (...) { return abi_exception(); }
 }
 
 void fhe_hip_ctx_destroy(fhe_hip_ctx *c) {
@@ -722,6 +726,7 @@ int fhe_hip_set_stream(fhe_hip_ctx *c, void *s) { TRY(check_ctx(c)); c->stream =
 int fhe_hip_sync(fhe_hip_ctx *c) { TRY(check_ctx(c)); HIPCHK(c, hipStreamSynchronize(c->stream)); return FHE_HIP_OK; }
 
 static int ntt_api(fhe_hip_ctx *c, uint64_t *limbs, const uint32_t *moduli_idx, size_t n_limbs, int mem_kind, bool inverse) {
+  try {
   TRY(check_ctx(c));
   if (n_limbs == 0) return FHE_HIP_OK;  // an empty batch is a no-op, whatever the pointers
   if (!limbs || !moduli_idx) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
@@ -738,11 +743,13 @@ static int ntt_api(fhe_hip_ctx *c, uint64_t *limbs, const uint32_t *moduli_idx, 
     TRY(ntt_run(c, p, inverse));
   }
   return st.finish();
+  } catch (...) { return abi_exception(); }
 }
 int fhe_hip_ntt_forward(fhe_hip_ctx *c, uint64_t *limbs, const uint32_t *idx, size_t n, int mk) { return ntt_api(c, limbs, idx, n, mk, false); }
 int fhe_hip_ntt_backward(fhe_hip_ctx *c, uint64_t *limbs, const uint32_t *idx, size_t n, int mk) { return ntt_api(c, limbs, idx, n, mk, true); }
 
 static int galois_api(fhe_hip_ctx *c, uint64_t *polys, uint32_t nlimbs, uint64_t galois, size_t batch, int mem_kind, bool ntt_domain) {
+  try {
   TRY(check_ctx(c));
   if (!polys) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   if (!(galois & 1) || galois >= 2 * c->N) FAIL(c, FHE_HIP_ERR_ARG, "galois must be odd and < 2N");
@@ -765,11 +772,13 @@ static int galois_api(fhe_hip_ctx *c, uint64_t *polys, uint32_t nlimbs, uint64_t
     LAUNCH(c, "galois_coeff", galois_coeff_kernel, grid, dim3(PW_THREADS), d, (const u64 *)tmp, (const PrimeC *)c->d_primes, c->logN, galois, nlimbs);
   }
   return st.finish();
+  } catch (...) { return abi_exception(); }
 }
 int fhe_hip_apply_galois(fhe_hip_ctx *c, uint64_t *p, uint32_t nl, uint64_t g, size_t b, int mk) { return galois_api(c, p, nl, g, b, mk, true); }
 int fhe_hip_apply_galois_non_ntt(fhe_hip_ctx *c, uint64_t *p, uint32_t nl, uint64_t g, size_t b, int mk) { return galois_api(c, p, nl, g, b, mk, false); }
 
 int fhe_hip_mod_up(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t Li, size_t batch, int mem_kind) {
+  try {
   TRY(check_ctx(c));
   if (!rop || !op) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   if (Li > c->L) FAIL(c, FHE_HIP_ERR_RANGE, "Only support mod up from normal primes");
@@ -784,9 +793,11 @@ int fhe_hip_mod_up(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t L
     HIPCHK(c, hipMemcpyAsync(drop + b * nl * N, dop + b * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream));
   TRY(dev_conv_to_special(c, drop, nl, Li, dop, Li, Li, (u32)batch));
   return st.finish();
+  } catch (...) { return abi_exception(); }
 }
 
 int fhe_hip_mod_down(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t L0, size_t batch, int mem_kind) {
+  try {
   TRY(check_ctx(c));
   if (!rop || !op) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   if (L0 < 1 || L0 > c->L || c->K < 1) FAIL(c, FHE_HIP_ERR_RANGE, "bad limb count");
@@ -798,9 +809,11 @@ int fhe_hip_mod_down(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t
   TRY(st.out(rop, batch * L0 * N * 8, &drop, false));
   TRY(dev_mod_down(c, drop, dop, L0, (u32)batch, nullptr, 2));
   return st.finish();
+  } catch (...) { return abi_exception(); }
 }
 
 int fhe_hip_conv_to_normal(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *sp, uint32_t L0, size_t batch, int mem_kind) {
+  try {
   TRY(check_ctx(c));
   if (!rop || !sp) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   if (L0 < 1 || L0 > c->L) FAIL(c, FHE_HIP_ERR_RANGE, "target limb count out of range");
@@ -812,9 +825,11 @@ int fhe_hip_conv_to_normal(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *sp, ui
   TRY(st.out(rop, batch * L0 * c->N * 8, &drop, false));
   TRY(dev_conv_to_normal(c, drop, L0, dsp, c->K, 0, (u32)batch));
   return st.finish();
+  } catch (...) { return abi_exception(); }
 }
 
 int fhe_hip_rescale(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t n, size_t batch, int mem_kind) {
+  try {
   TRY(check_ctx(c));
   if (!rop || !op) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   if (n < 2 || n > c->M) FAIL(c, FHE_HIP_ERR_RANGE, "Already in the last moduli.");
@@ -826,6 +841,7 @@ int fhe_hip_rescale(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t 
   TRY(st.out(rop, batch * (n - 1) * N * 8, &drop, false));
   TRY(dev_rescale(c, drop, dop, n, (u32)batch, 2));
   return st.finish();
+  } catch (...) { return abi_exception(); }
 }
 
 static int load_key(fhe_hip_ctx *c, u64 **dst, const uint64_t *src, size_t limbs, const u32 *midx, u32 mper, int mem_kind) {
@@ -837,6 +853,7 @@ static int load_key(fhe_hip_ctx *c, u64 **dst, const uint64_t *src, size_t limbs
 }
 
 int fhe_hip_load_mult_key(fhe_hip_ctx *c, const uint64_t *beta, const uint64_t *alpha, int mem_kind) {
+  try {
   TRY(check_ctx(c));
   if (!beta || !alpha) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   // [L][L][N]: limb id = j*L + i uses modulus i = id % L
@@ -844,9 +861,11 @@ int fhe_hip_load_mult_key(fhe_hip_ctx *c, const uint64_t *beta, const uint64_t *
   TRY(load_key(c, &c->d_mk_alpha, alpha, (size_t)c->L * c->L, c->d_iota, c->L, mem_kind));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return FHE_HIP_OK;
+  } catch (...) { return abi_exception(); }
 }
 
 int fhe_hip_load_rot_key(fhe_hip_ctx *c, uint64_t galois, const uint64_t *beta, const uint64_t *alpha, int mem_kind) {
+  try {
   TRY(check_ctx(c));
   if (!beta || !alpha) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   if (c->K < 1) FAIL(c, FHE_HIP_ERR_RANGE, "rotation keys need special primes");
@@ -856,9 +875,11 @@ int fhe_hip_load_rot_key(fhe_hip_ctx *c, uint64_t galois, const uint64_t *beta, 
   TRY(load_key(c, &rk.alpha_m, alpha, c->M, c->d_iota, c->M, mem_kind));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return FHE_HIP_OK;
+  } catch (...) { return abi_exception(); }
 }
 
 int fhe_hip_add(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t nlimbs, size_t batch, int mem_kind) {
+  try {
   TRY(check_ctx(c));
   if (!rop || !op) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   if (nlimbs < 1 || nlimbs > c->M) FAIL(c, FHE_HIP_ERR_RANGE, "bad limb count");
@@ -870,9 +891,11 @@ int fhe_hip_add(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t nlim
   TRY(st.out(rop, bytes, &drop, true));
   LAUNCH(c, "add", add_kernel, pw_grid(c, nlimbs, (u32)batch), dim3(PW_THREADS), drop, dop, (const PrimeC *)c->d_primes, c->N);
   return st.finish();
+  } catch (...) { return abi_exception(); }
 }
 
 int fhe_hip_multiply_plain(fhe_hip_ctx *c, uint64_t *ct, const uint64_t *pt, uint32_t nlimbs, size_t batch, int mem_kind) {
+  try {
   TRY(check_ctx(c));
   if (!ct || !pt) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   if (nlimbs < 1 || nlimbs > c->M) FAIL(c, FHE_HIP_ERR_RANGE, "bad limb count");
@@ -883,6 +906,7 @@ int fhe_hip_multiply_plain(fhe_hip_ctx *c, uint64_t *ct, const uint64_t *pt, uin
   TRY(st.out(ct, batch * 2 * nlimbs * c->N * 8, &dct, true));
   LAUNCH_SP(c, "mul_plain", mul_plain_kernel, pw_grid(c, 2 * nlimbs, (u32)batch), dim3(PW_THREADS), dct, dpt, (const PrimeC *)c->d_primes, nlimbs, c->N);
   return st.finish();
+  } catch (...) { return abi_exception(); }
 }
 
 static int check_li(fhe_hip_ctx *c, uint32_t Li, uint32_t min) {
@@ -892,6 +916,7 @@ static int check_li(fhe_hip_ctx *c, uint32_t Li, uint32_t min) {
 }
 
 int fhe_hip_cross_mult(fhe_hip_ctx *c, uint64_t *out3, const uint64_t *c0, const uint64_t *c1, uint32_t Li, size_t batch, int mem_kind) {
+  try {
   TRY(check_ctx(c));
   if (!out3 || !c0 || !c1) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   TRY(check_li(c, Li, 1));
@@ -903,9 +928,11 @@ int fhe_hip_cross_mult(fhe_hip_ctx *c, uint64_t *out3, const uint64_t *c0, const
   TRY(st.out(out3, ctb / 2 * 3, &dout, false));
   LAUNCH_SP(c, "cross_mult", cross_mult_kernel, pw_grid(c, Li, (u32)batch), dim3(PW_THREADS), dout, d0, d1, (const PrimeC *)c->d_primes, Li, c->N);
   return st.finish();
+  } catch (...) { return abi_exception(); }
 }
 
 int fhe_hip_relin_only(fhe_hip_ctx *c, uint64_t *out, const uint64_t *ct3, uint32_t Li, size_t batch, int mem_kind) {
+  try {
   TRY(check_ctx(c));
   if (!out || !ct3) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   TRY(check_li(c, Li, 1));
@@ -917,9 +944,11 @@ int fhe_hip_relin_only(fhe_hip_ctx *c, uint64_t *out, const uint64_t *ct3, uint3
   TRY(st.out(out, batch * 2 * limb_b, &dout, false));
   TRY(dev_relin(c, dout, din, Li, (u32)batch));
   return st.finish();
+  } catch (...) { return abi_exception(); }
 }
 
 int fhe_hip_relinearize(fhe_hip_ctx *c, uint64_t *out, const uint64_t *ct3, uint32_t Li, size_t batch, int mem_kind) {
+  try {
   TRY(check_ctx(c));
   if (!out || !ct3) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   TRY(check_li(c, Li, 2));
@@ -934,9 +963,11 @@ int fhe_hip_relinearize(fhe_hip_ctx *c, uint64_t *out, const uint64_t *ct3, uint
   TRY(dev_relin(c, rl, din, Li, (u32)batch));
   TRY(dev_rescale_ntt(c, dout, rl, Li, (u32)batch));
   return st.finish();
+  } catch (...) { return abi_exception(); }
 }
 
 int fhe_hip_mul_relin_rescale(fhe_hip_ctx *c, uint64_t *out, const uint64_t *c0, const uint64_t *c1, uint32_t Li, size_t batch, int mem_kind) {
+  try {
   TRY(check_ctx(c));
   if (!out || !c0 || !c1) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   TRY(check_li(c, Li, 2));
@@ -949,9 +980,11 @@ int fhe_hip_mul_relin_rescale(fhe_hip_ctx *c, uint64_t *out, const uint64_t *c0,
   TRY(st.out(out, batch * 2 * (Li - 1) * N * 8, &dout, false));
   TRY(dev_mul_relin_rescale(c, dout, d0, d1, Li, (u32)batch));
   return st.finish();
+  } catch (...) { return abi_exception(); }
 }
 
 static int rotate_api(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind, bool non_ntt) {
+  try {
   TRY(check_ctx(c));
   if (!ct) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   if (galois == 0) return FHE_HIP_OK;  // evaluator.cpp:303-304
@@ -964,6 +997,7 @@ static int rotate_api(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li
   TRY(st.out(ct, batch * 2 * Li * c->N * 8, &d, true));
   TRY(dev_rotate(c, galois, d, Li, (u32)batch, non_ntt));
   return st.finish();
+  } catch (...) { return abi_exception(); }
 }
 int fhe_hip_rotate(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind) {
   return rotate_api(c, galois, ct, Li, batch, mem_kind, false);
@@ -976,6 +1010,7 @@ int fhe_hip_rotate_non_ntt(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32
 // in chunks through the ordinary host-pointer entry points (which stage through that context's device buffers).
 int fhe_hip_batch_run(fhe_hip_ctx *const *ctxs, uint32_t n_ctx, int op, uint64_t *out, const uint64_t *in0, const uint64_t *in1,
                       uint64_t galois, uint32_t Li, size_t batch, int mem_kind) {
+  try {
   if (!ctxs || n_ctx == 0) return FHE_HIP_ERR_ARG;
   for (u32 g = 0; g < n_ctx; ++g) if (!ctxs[g]) return FHE_HIP_ERR_ARG;
   fhe_hip_ctx *c0 = ctxs[0];
@@ -1006,14 +1041,22 @@ int fhe_hip_batch_run(fhe_hip_ctx *const *ctxs, uint32_t n_ctx, int op, uint64_t
     }
   };
   std::vector<std::thread> workers;
-  for (u32 g = 1; g < n_ctx; ++g) workers.emplace_back(slice, g);
+  u32 started = 1;
+  try {  // no exception may cross the C ABI: a slice whose thread cannot be started runs on the calling thread
+    workers.reserve(n_ctx);
+    for (; started < n_ctx; ++started) workers.emplace_back(slice, started);
+  } catch (...) {
+  }
   slice(0);
+  for (u32 g = started; g < n_ctx; ++g) slice(g);
   for (auto &w : workers) w.join();
   for (u32 g = 0; g < n_ctx; ++g) if (rc[g] != FHE_HIP_OK) return rc[g];
   return FHE_HIP_OK;
+  } catch (...) { return abi_exception(); }
 }
 
 int fhe_hip_load_mixed_rot_key(fhe_hip_ctx *c, uint64_t galois, const uint64_t *beta, const uint64_t *alpha, int mem_kind) {
+  try {
   TRY(check_ctx(c));
   if (!beta || !alpha) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   if (c->K < 1) FAIL(c, FHE_HIP_ERR_RANGE, "mixed rotation keys need one special prime");
@@ -1024,9 +1067,11 @@ int fhe_hip_load_mixed_rot_key(fhe_hip_ctx *c, uint64_t galois, const uint64_t *
   TRY(load_key(c, &rk.alpha_m, alpha, (size_t)c->L * (c->L + 1), c->d_iota, c->L + 1, mem_kind));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return FHE_HIP_OK;
+  } catch (...) { return abi_exception(); }
 }
 
 int fhe_hip_rotate_mixed(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind) {
+  try {
   TRY(check_ctx(c));
   if (!ct) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   if (galois == 0) return FHE_HIP_OK;  // evaluator.cpp:317-318
@@ -1039,9 +1084,11 @@ int fhe_hip_rotate_mixed(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t
   TRY(st.out(ct, batch * 2 * Li * c->N * 8, &d, true));
   TRY(dev_rotate_mixed(c, galois, d, Li, (u32)batch));
   return st.finish();
+  } catch (...) { return abi_exception(); }
 }
 
 int fhe_hip_decrypt(fhe_hip_ctx *c, uint64_t *out, const uint64_t *ct, const uint64_t *sx, uint32_t Li, size_t batch, int mem_kind) {
+  try {
   TRY(check_ctx(c));
   if (!out || !ct || !sx) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   if (Li < 1 || Li > c->L) FAIL(c, FHE_HIP_ERR_RANGE, "Impossible.");  // decryptor.cpp:17-18
@@ -1055,10 +1102,12 @@ int fhe_hip_decrypt(fhe_hip_ctx *c, uint64_t *out, const uint64_t *ct, const uin
   LAUNCH_SP(c, "decrypt_mac", decrypt_mac_kernel, pw_grid(c, Li, (u32)batch), dim3(PW_THREADS), dout, dct, dsx, (const PrimeC *)c->d_primes, Li, N);
   TRY(ntt_simple(c, dout, c->d_iota, Li, (u32)batch, (u64)Li * N, true));  // rop->backward(), decryptor.cpp:36
   return st.finish();
+  } catch (...) { return abi_exception(); }
 }
 
 int fhe_hip_encrypt(fhe_hip_ctx *c, uint64_t *ct, const uint64_t *u, const uint64_t *e0m, const uint64_t *e1, const uint64_t *pk_b,
                     const uint64_t *pk_a, uint32_t Li, size_t batch, int mem_kind) {
+  try {
   TRY(check_ctx(c));
   if (!ct || !u || !e0m || !e1 || !pk_b || !pk_a) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   if (Li < 1 || Li > c->L) FAIL(c, FHE_HIP_ERR_RANGE, "bad limb count");
@@ -1088,17 +1137,21 @@ int fhe_hip_encrypt(fhe_hip_ctx *c, uint64_t *ct, const uint64_t *u, const uint6
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   return FHE_HIP_OK;
+  } catch (...) { return abi_exception(); }
 }
 
 int fhe_hip_profile_enable(fhe_hip_ctx *c, int on) { TRY(check_ctx(c)); c->prof = on != 0; return FHE_HIP_OK; }
 int fhe_hip_profile_reset(fhe_hip_ctx *c) {
+  try {
   TRY(check_ctx(c));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   prof_drain(c);
   for (auto &e : c->prof_entries) { e.launches = 0; e.total_ms = 0; }
   return FHE_HIP_OK;
+  } catch (...) { return abi_exception(); }
 }
 int fhe_hip_profile_get(fhe_hip_ctx *c, const char **names, uint64_t *launches, double *total_ms, int cap) {
+  try {
   if (!c) return FHE_HIP_ERR_ARG;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
@@ -1109,6 +1162,7 @@ int fhe_hip_profile_get(fhe_hip_ctx *c, const char **names, uint64_t *launches, 
     ++n;
   }
   return n;
+  } catch (...) { return abi_exception(); }
 }
 
 }  // extern "C"
