@@ -23,6 +23,23 @@ __global__ __launch_bounds__(256) void k(ulonglong2 *dst, const ulonglong2 *src,
   if (MODE == 2 && acc.x == 0x1234567 && acc.y == 7) dst[0] = acc;  // keeps the loads alive
 }
 
+// the same with 8 B per lane (the access width of the NTT passes' strided loads)
+__global__ __launch_bounds__(256) void k8(unsigned long long *dst, const unsigned long long *src, size_t n, int per) {
+  size_t i = (size_t)blockIdx.x * 256 * per + threadIdx.x;
+  for (int r = 0; r < per; ++r, i += 256)
+    if (i < n) dst[i] = src[i] + 1;
+}
+// 8 loads of 8 B in flight per lane, then 4 stores of 16 B (the row pass's memory shape without its arithmetic)
+__global__ __launch_bounds__(256) void krow(unsigned long long *dst, const unsigned long long *src) {
+  const size_t row = (size_t)blockIdx.x * 8 + (threadIdx.x >> 5), t = threadIdx.x & 31;
+  const unsigned long long *s = src + row * 256;
+  unsigned long long e[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = s[t + 32 * k];
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) *reinterpret_cast<ulonglong2 *>(dst + row * 256 + 64 * (k / 2) + 2 * t) = ulonglong2{e[k] + 1, e[k + 1] ^ 3};
+}
+
 int main() {
   const size_t bytes = (size_t)512 << 19;  // 512 limbs x 512 KiB
   const size_t n = bytes / 16;
@@ -48,5 +65,30 @@ int main() {
       const double moved = (mode < 2 ? 2.0 : 1.0) * bytes;
       printf("%-14s per=%-2d grid=%-7d %.4f ms  %.2f TB/s\n", names[mode], per, grid, best, moved / (best * 1e-3) / 1e12);
     }
+  for (int per : {1, 4}) {
+    const size_t n8 = bytes / 8;
+    const int grid = (int)((n8 + 256 * (size_t)per - 1) / (256 * (size_t)per));
+    float best = 1e9f;
+    for (int rep = 0; rep < 6; ++rep) {
+      CHECK(hipEventRecord(e0));
+      k8<<<grid, 256>>>((unsigned long long *)a, (const unsigned long long *)a, n8, per);
+      CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+      float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep && ms < best) best = ms;
+    }
+    printf("%-14s per=%-2d grid=%-7d %.4f ms  %.2f TB/s\n", "in-place 8 B", per, grid, best, 2.0 * bytes / (best * 1e-3) / 1e12);
+  }
+  {
+    const int grid = (int)(bytes / 8 / 256 / 8);
+    float best = 1e9f;
+    for (int rep = 0; rep < 6; ++rep) {
+      CHECK(hipEventRecord(e0));
+      krow<<<grid, 256>>>((unsigned long long *)a, (const unsigned long long *)a);
+      CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+      float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep && ms < best) best = ms;
+    }
+    printf("%-14s grid=%-7d %.4f ms  %.2f TB/s\n", "row-pass shape", grid, best, 2.0 * bytes / (best * 1e-3) / 1e12);
+  }
   return 0;
 }
