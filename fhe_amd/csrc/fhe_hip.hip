@@ -69,6 +69,8 @@ struct fhe_hip_ctx {
   size_t ws_bytes[6] = {0, 0, 0, 0, 0, 0};
   void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[4] = {0, 0, 0, 0};
+  // moduli_idx of the last fhe_hip_ntt_* call, kept on both sides: a repeated call with the same indices uploads nothing
+  u32 *d_idx = nullptr; size_t d_idx_cap = 0; std::vector<u32> h_idx;
   // profiling
   bool prof = false;
   std::vector<ProfEntry> prof_entries;
@@ -719,6 +721,7 @@ void fhe_hip_ctx_destroy(fhe_hip_ctx *c) {
   for (auto &kv : c->galois_perm) hipFree(kv.second);
   for (void *p : c->ws) if (p) hipFree(p);
   for (void *p : c->stage) if (p) hipFree(p);
+  if (c->d_idx) hipFree(c->d_idx);
   delete c;
 }
 
@@ -734,9 +737,17 @@ static int ntt_api(fhe_hip_ctx *c, uint64_t *limbs, const uint32_t *moduli_idx, 
   Staged st(c, mem_kind);
   u64 *d = nullptr;
   TRY(st.out(limbs, n_limbs * c->N * 8, &d, true));
-  TRY(ensure_stage(c, 3, n_limbs * sizeof(u32)));
-  u32 *dm = (u32 *)c->stage[3];
-  HIPCHK(c, hipMemcpyAsync(dm, moduli_idx, n_limbs * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+  if (c->h_idx.size() != n_limbs || std::memcmp(c->h_idx.data(), moduli_idx, n_limbs * sizeof(u32)) != 0) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // a previous upload or a kernel may still read the old copies
+    if (c->d_idx_cap < n_limbs) {
+      if (c->d_idx) { HIPCHK(c, hipFree(c->d_idx)); c->d_idx = nullptr; c->d_idx_cap = 0; }
+      HIPCHK(c, hipMalloc((void **)&c->d_idx, n_limbs * sizeof(u32)));
+      c->d_idx_cap = n_limbs;
+    }
+    c->h_idx.assign(moduli_idx, moduli_idx + n_limbs);
+    HIPCHK(c, hipMemcpyAsync(c->d_idx, c->h_idx.data(), n_limbs * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+  }
+  u32 *dm = c->d_idx;
   for (size_t off = 0; off < n_limbs; off += 32768) {
     const u32 n = (u32)((n_limbs - off < 32768) ? n_limbs - off : 32768);
     NttPlan p{d + off * c->N, d + off * c->N, dm + off, 1, n, n, n, 1, 0, 0};

@@ -14,8 +14,8 @@ done
 cd /tmp && export TMPDIR=/tmp
 for wl in c3 ntt c4; do
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats_$wl.log 2>&1 || { tail -20 $OUT/stats_$wl.log; exit 1; }
-  timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$wl -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > $OUT/fetch_$wl.log 2>&1 || { tail -5 $OUT/fetch_$wl.log; exit 1; }
-  timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$wl -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > $OUT/write_$wl.log 2>&1 || { tail -5 $OUT/write_$wl.log; exit 1; }
+  timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$wl -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 2 --warmup 1 --prewarm 0 --no-cpu-baseline > $OUT/fetch_$wl.log 2>&1 || { tail -5 $OUT/fetch_$wl.log; exit 1; }
+  timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_$wl -- python3 $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 2 --warmup 1 --prewarm 0 --no-cpu-baseline > $OUT/write_$wl.log 2>&1 || { tail -5 $OUT/write_$wl.log; exit 1; }
 done
 for wl in c3 ntt c4; do
   mkdir -p $OUT/pmc_$wl && cp -r $OUT/fetch_$wl $OUT/write_$wl $OUT/pmc_$wl/ 2>/dev/null
