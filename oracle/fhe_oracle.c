@@ -706,7 +706,7 @@ void orc_keygen_mixed_rot(const orc_ctx *c, u64 *beta, u64 *alpha, const u64 *sx
 void orc_encrypt(const orc_ctx *c, u64 *bx, u64 *ax, const u64 *msg, uint32_t Li, const u64 *pk_b, const u64 *pk_a, u64 seed) {
   /* encryptor.cpp:9-37 */
   const size_t N = c->N; u64 st = seed;
-  int *v = (int *)malloc(N * sizeof(int));
+  int *v = (int *)calloc(N, sizeof(int));
   u64 *u = (u64 *)malloc((size_t)Li * N * 8);
   sample_zo(v, N, &st); set_small(c, u, v, 0, Li);
   sample_gauss(v, N, &st); set_small(c, bx, v, 0, Li);
