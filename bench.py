@@ -29,7 +29,7 @@ WORKLOADS = {
     #        logN  L   K   Li  default batch
     "c3": (16, 30, 1, 30, 16),
     "c5": (15, 16, 1, 16, 64),
-    "c4": (16, 30, 30, 30, 16),
+    "c4": (16, 30, 30, 30, 64),
     "ntt": (16, 8, 0, 8, 512),
     "c2": (14, 8, 0, 8, 8192),
 }
