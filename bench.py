@@ -235,7 +235,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ctx.profile_enable(True)
+    ctx.profile_enable(not os.environ.get("FHE_BENCH_NOPROF"))  # development switch: cost of the per-launch events
     ctx.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):

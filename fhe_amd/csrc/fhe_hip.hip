@@ -69,6 +69,8 @@ struct fhe_hip_ctx {
   size_t ws_bytes[6] = {0, 0, 0, 0, 0, 0};
   void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[4] = {0, 0, 0, 0};
+  // per-launch timing: consecutive launches share an event (end of one = start of the next) while nothing else was enqueued
+  hipEvent_t chain_ev = nullptr; bool chain_valid = false; std::vector<hipEvent_t> prof_events;
   // moduli_idx of the last fhe_hip_ntt_* call, kept on both sides: a repeated call with the same indices uploads nothing
   u32 *d_idx = nullptr; size_t d_idx_cap = 0; std::vector<u32> h_idx;
   // profiling
@@ -151,18 +153,32 @@ void prof_drain(fhe_hip_ctx *c) {
       float ms = 0;
       hipEventElapsedTime(&ms, pr.first, pr.second);
       e.total_ms += ms; e.launches += 1;
-      hipEventDestroy(pr.first); hipEventDestroy(pr.second);
     }
     e.pending.clear();
   }
+  for (hipEvent_t ev : c->prof_events) hipEventDestroy(ev);
+  c->prof_events.clear();
+  c->chain_valid = false;
+}
+// anything the library enqueues besides a timed launch ends the chain of shared events (so does every entry: check_ctx)
+inline hipError_t prof_chain_break(fhe_hip_ctx *c) { c->chain_valid = false; return hipSuccess; }
+inline hipEvent_t prof_event(fhe_hip_ctx *c) {
+  hipEvent_t ev = nullptr;
+  hipEventCreate(&ev);
+  hipEventRecord(ev, c->stream);
+  c->prof_events.push_back(ev);
+  return ev;
 }
 
 #define LAUNCH(c, name, kern, grid, block, ...)                                                  \
   do {                                                                                           \
-    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;                                                   \
-    if ((c)->prof) { hipEventCreate(&ev0_); hipEventCreate(&ev1_); hipEventRecord(ev0_, (c)->stream); } \
+    hipEvent_t ev0_ = nullptr;                                                                   \
+    if ((c)->prof) ev0_ = (c)->chain_valid ? (c)->chain_ev : prof_event(c);                      \
     hipLaunchKernelGGL(kern, grid, block, 0, (c)->stream, __VA_ARGS__);                          \
-    if ((c)->prof) { hipEventRecord(ev1_, (c)->stream); prof_entry((c), name)->pending.push_back({ev0_, ev1_}); } \
+    if ((c)->prof) {                                                                             \
+      (c)->chain_ev = prof_event(c); (c)->chain_valid = true;                                    \
+      prof_entry((c), name)->pending.push_back({ev0_, (c)->chain_ev});                           \
+    }                                                                                            \
     HIPCHK(c, hipGetLastError());                                                                \
   } while (0)
 
@@ -289,7 +305,7 @@ struct Staged {
     if (kind == FHE_HIP_MEM_DEVICE) { *dev = (const u64 *)p; return FHE_HIP_OK; }
     int slot = next++;
     TRY(ensure_stage(c, slot, bytes));
-    HIPCHK(c, hipMemcpyAsync(c->stage[slot], p, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(c->stage[slot], p, bytes, hipMemcpyHostToDevice, c->stream)));
     *dev = (const u64 *)c->stage[slot];
     return FHE_HIP_OK;
   }
@@ -297,14 +313,14 @@ struct Staged {
     if (kind == FHE_HIP_MEM_DEVICE) { *dev = (u64 *)p; return FHE_HIP_OK; }
     int slot = next++;
     TRY(ensure_stage(c, slot, bytes));
-    if (also_in) HIPCHK(c, hipMemcpyAsync(c->stage[slot], p, bytes, hipMemcpyHostToDevice, c->stream));
+    if (also_in) HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(c->stage[slot], p, bytes, hipMemcpyHostToDevice, c->stream)));
     *dev = (u64 *)c->stage[slot];
     outs.push_back({p, c->stage[slot], bytes});
     return FHE_HIP_OK;
   }
   int finish() {
     if (kind == FHE_HIP_MEM_DEVICE) return FHE_HIP_OK;
-    for (auto &o : outs) HIPCHK(c, hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, c->stream));
+    for (auto &o : outs) HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, c->stream)));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FHE_HIP_OK;
   }
@@ -312,6 +328,7 @@ struct Staged {
 
 int check_ctx(fhe_hip_ctx *c) {
   if (!c) return FHE_HIP_ERR_ARG;
+  c->chain_valid = false;  // the caller may have enqueued work of its own on the stream since the last call
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) { c->err = std::string("hipSetDevice: ") + hipGetErrorString(e); return FHE_HIP_ERR_HIP; }
   return FHE_HIP_OK;
@@ -480,7 +497,7 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
   const bool fused = !identity && !non_ntt;
   const u64 g_bstride = fused ? (u64)Li * N : (u64)2 * Li * N;
   if (identity) {
-    HIPCHK(c, hipMemcpyAsync(g, ct, ctb, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(g, ct, ctb, hipMemcpyDeviceToDevice, c->stream)));
   } else if (non_ntt) {
     LAUNCH(c, "galois_coeff", galois_coeff_kernel, dim3((unsigned)(N / PW_THREADS), 2 * Li, batch), dim3(PW_THREADS), g, (const u64 *)ct,
            (const PrimeC *)c->d_primes, c->logN, galois, Li);
@@ -496,7 +513,7 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
     // ax_g is already in the power basis (:537): mod up, then forward NTT of all Li+K limbs (:539-542)
     TRY(dev_conv_to_special(c, e0, nl, Li, g + (size_t)Li * N, 2 * Li, Li, batch));
     for (u32 b = 0; b < batch; ++b)
-      HIPCHK(c, hipMemcpyAsync(e0 + (size_t)b * nl * N, g + ((size_t)b * 2 + 1) * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(e0 + (size_t)b * nl * N, g + ((size_t)b * 2 + 1) * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream)));
     NttPlan pf{e0, e0, c->d_rotmap + (size_t)Li * c->M, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
     TRY(ntt_run(c, pf, false));
   } else {
@@ -575,7 +592,7 @@ int dev_rotate_mixed(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch) {
   TRY(ensure_ws(c, 4, (size_t)batch * 2 * nout * N * 8));          // ans_bx / ans_ax over Li+1 limbs
   u64 *g = (u64 *)c->ws[3], *pw = (u64 *)c->ws[0], *t = (u64 *)c->ws[1], *ans = (u64 *)c->ws[4];
   if (galois == 1) {
-    HIPCHK(c, hipMemcpyAsync(g, ct, ctb, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(g, ct, ctb, hipMemcpyDeviceToDevice, c->stream)));
   } else {
     u32 *perm = nullptr;
     TRY(get_galois_perm(c, galois, &perm));
@@ -745,7 +762,7 @@ static int ntt_api(fhe_hip_ctx *c, uint64_t *limbs, const uint32_t *moduli_idx, 
       c->d_idx_cap = n_limbs;
     }
     c->h_idx.assign(moduli_idx, moduli_idx + n_limbs);
-    HIPCHK(c, hipMemcpyAsync(c->d_idx, c->h_idx.data(), n_limbs * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(c->d_idx, c->h_idx.data(), n_limbs * sizeof(u32), hipMemcpyHostToDevice, c->stream)));
   }
   u32 *dm = c->d_idx;
   for (size_t off = 0; off < n_limbs; off += 32768) {
@@ -772,7 +789,7 @@ static int galois_api(fhe_hip_ctx *c, uint64_t *polys, uint32_t nlimbs, uint64_t
   TRY(st.out(polys, bytes, &d, true));
   TRY(ensure_ws(c, 0, bytes));
   u64 *tmp = (u64 *)c->ws[0];
-  HIPCHK(c, hipMemcpyAsync(tmp, d, bytes, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(tmp, d, bytes, hipMemcpyDeviceToDevice, c->stream)));
   dim3 grid((unsigned)(c->N / PW_THREADS), nlimbs, (unsigned)batch);
   if (ntt_domain) {
     u32 *perm = nullptr;
@@ -801,7 +818,7 @@ int fhe_hip_mod_up(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t L
   TRY(st.in(op, batch * Li * N * 8, &dop));
   TRY(st.out(rop, batch * nl * N * 8, &drop, false));
   for (size_t b = 0; b < batch; ++b)
-    HIPCHK(c, hipMemcpyAsync(drop + b * nl * N, dop + b * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(drop + b * nl * N, dop + b * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream)));
   TRY(dev_conv_to_special(c, drop, nl, Li, dop, Li, Li, (u32)batch));
   return st.finish();
   } catch (...) { return abi_exception(); }
@@ -858,7 +875,7 @@ int fhe_hip_rescale(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t 
 static int load_key(fhe_hip_ctx *c, u64 **dst, const uint64_t *src, size_t limbs, const u32 *midx, u32 mper, int mem_kind) {
   const size_t bytes = limbs * c->N * 8;
   if (!*dst) HIPCHK(c, hipMalloc((void **)dst, bytes));
-  HIPCHK(c, hipMemcpyAsync(*dst, src, bytes, mem_kind == FHE_HIP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(*dst, src, bytes, mem_kind == FHE_HIP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream)));
   LAUNCH_SP(c, "to_mont", to_mont_kernel, pw_grid(c, (u32)limbs, 1), dim3(PW_THREADS), *dst, (const PrimeC *)c->d_primes, midx, mper, c->N);
   return FHE_HIP_OK;
 }
@@ -1132,19 +1149,19 @@ int fhe_hip_encrypt(fhe_hip_ctx *c, uint64_t *ct, const uint64_t *u, const uint6
   u64 *uh = (u64 *)c->ws[0], *dct = mem_kind == FHE_HIP_MEM_DEVICE ? (u64 *)ct : (u64 *)c->ws[3];
   u64 *dpk = (u64 *)c->ws[4];
   const hipMemcpyKind in_kind = mem_kind == FHE_HIP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  HIPCHK(c, hipMemcpyAsync(uh, u, batch * pb, in_kind, c->stream));
+  HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(uh, u, batch * pb, in_kind, c->stream)));
   for (size_t b = 0; b < batch; ++b) {
-    HIPCHK(c, hipMemcpyAsync(dct + b * 2 * Li * N, e0m + b * Li * N, pb, in_kind, c->stream));
-    HIPCHK(c, hipMemcpyAsync(dct + (b * 2 + 1) * Li * N, e1 + b * Li * N, pb, in_kind, c->stream));
+    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(dct + b * 2 * Li * N, e0m + b * Li * N, pb, in_kind, c->stream)));
+    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(dct + (b * 2 + 1) * Li * N, e1 + b * Li * N, pb, in_kind, c->stream)));
   }
-  HIPCHK(c, hipMemcpyAsync(dpk, pk_b, pb, in_kind, c->stream));
-  HIPCHK(c, hipMemcpyAsync(dpk + (size_t)Li * N, pk_a, pb, in_kind, c->stream));
+  HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(dpk, pk_b, pb, in_kind, c->stream)));
+  HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(dpk + (size_t)Li * N, pk_a, pb, in_kind, c->stream)));
   TRY(ntt_simple(c, uh, c->d_iota, Li, (u32)batch, (u64)Li * N, false));           // u.forward(), encryptor.cpp:16
   TRY(ntt_simple(c, dct, c->d_iota, Li, 2 * (u32)batch, (u64)Li * N, false));     // bx/ax.forward_lazy(), :30,34
   LAUNCH_SP(c, "encrypt_mac", encrypt_mac_kernel, pw_grid(c, Li, (u32)batch), dim3(PW_THREADS), dct, (const u64 *)uh, (const u64 *)dpk,
             (const u64 *)(dpk + (size_t)Li * N), (const PrimeC *)c->d_primes, Li, N);
   if (mem_kind != FHE_HIP_MEM_DEVICE) {
-    HIPCHK(c, hipMemcpyAsync(ct, dct, batch * 2 * pb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(ct, dct, batch * 2 * pb, hipMemcpyDeviceToHost, c->stream)));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   return FHE_HIP_OK;
