@@ -30,7 +30,7 @@ WORKLOADS = {
     "c3": (16, 30, 1, 30, 16),
     "c5": (15, 16, 1, 16, 64),
     "c4": (16, 30, 30, 30, 64),
-    "ntt": (16, 8, 0, 8, 512),
+    "ntt": (16, 8, 0, 8, 2048),
     "c2": (14, 8, 0, 8, 8192),
 }
 

@@ -23,6 +23,6 @@ for wl in c3 ntt c4; do
   rm -rf $OUT/pmc_$wl
 done
 python3 $GRAFT_REPO_ROOT/tools/make_traffic_json.py $OUT/pmc_summary_c3.txt c3 "c3, default batch per launch, N=2^16 Li=30" $OUT/traffic_c3.json relin_rows
-python3 $GRAFT_REPO_ROOT/tools/make_traffic_json.py $OUT/pmc_summary_ntt.txt ntt "ntt, 512 limbs/launch, N=2^16" $OUT/traffic_ntt.json "ntt_cols_kernel<true, false" "ntt_rows8_fwd_kernel<true, 0"
+python3 $GRAFT_REPO_ROOT/tools/make_traffic_json.py $OUT/pmc_summary_ntt.txt ntt "ntt, 2048 limbs/launch, N=2^16" $OUT/traffic_ntt.json "ntt_cols_kernel<true, false" "ntt_rows8_fwd_kernel<true, 0"
 python3 $GRAFT_REPO_ROOT/tools/make_traffic_json.py $OUT/pmc_summary_c4.txt c4 "c4, default batch per launch, N=2^16 Li=K=30 (one base-conversion launch)" $OUT/traffic_c4.json bconv_kernel
 cat $OUT/pmc_summary_c3.txt | head -40
