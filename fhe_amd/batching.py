@@ -31,29 +31,41 @@ class ShardedBatch:
     def bounds(self, n_items, rank=None):
         return shard_bounds(n_items, self.world, self.rank if rank is None else rank)
 
-    def _p2p(self, ops):
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+    def _p2p_start(self, ops):
+        return dist.batch_isend_irecv(ops) if ops else []
 
-    def scatter(self, full, n_items, item_shape, dtype=torch.int64):
-        """Root holds `full` = [n_items, *item_shape]; every rank returns its slice [hi-lo, *item_shape]."""
+    @staticmethod
+    def _p2p_wait(reqs):
+        for req in reqs:
+            req.wait()  # RCCL: the current stream waits, the host does not
+
+    def _p2p(self, ops):
+        self._p2p_wait(self._p2p_start(ops))
+
+    def scatter_start(self, full, n_items, item_shape, dtype=torch.int64):
+        """Begin a scatter: returns (local slice, pending requests, buffers to keep alive).  The slice may be used after
+        `_p2p_wait(requests)`."""
         lo, hi = self.bounds(n_items)
         if self.world == 1:
-            return full[lo:hi]
+            return full[lo:hi], [], None
         if self.rank == self.root:
-            ops = []
+            ops, keep = [], []
             for r in range(self.world):
                 if r == self.root:
                     continue
                 rlo, rhi = self.bounds(n_items, r)
                 if rhi > rlo:
-                    ops.append(dist.P2POp(dist.isend, full[rlo:rhi].contiguous(), r, self.group))
-            self._p2p(ops)
-            return full[lo:hi]
+                    keep.append(full[rlo:rhi].contiguous())
+                    ops.append(dist.P2POp(dist.isend, keep[-1], r, self.group))
+            return full[lo:hi], self._p2p_start(ops), keep
         local = torch.empty((hi - lo,) + tuple(item_shape), dtype=dtype, device=self.device)
-        if hi > lo:
-            self._p2p([dist.P2POp(dist.irecv, local, self.root, self.group)])
+        reqs = self._p2p_start([dist.P2POp(dist.irecv, local, self.root, self.group)]) if hi > lo else []
+        return local, reqs, None
+
+    def scatter(self, full, n_items, item_shape, dtype=torch.int64):
+        """Root holds `full` = [n_items, *item_shape]; every rank returns its slice [hi-lo, *item_shape]."""
+        local, reqs, _keep = self.scatter_start(full, n_items, item_shape, dtype)
+        self._p2p_wait(reqs)
         return local
 
     def gather(self, local, n_items, item_shape, dtype=torch.int64):
@@ -89,9 +101,21 @@ class ShardedBatch:
         larger than one GPU's memory can stream through."""
         outs = []
         step = max(1, n_items if not chunk else chunk * self.world)
-        for c0 in range(0, max(n_items, 1), step):
+        starts = list(range(0, max(n_items, 1), step))
+
+        def begin(c0):
             n = min(step, n_items - c0)
-            local_in = [self.scatter(None if x is None else x[c0:c0 + n], n, shp) for x, shp in zip(inputs, in_shapes)]
+            return n, [self.scatter_start(None if x is None else x[c0:c0 + n], n, shp) for x, shp in zip(inputs, in_shapes)]
+
+        # the scatter of chunk k+1 is issued before chunk k is computed, so on GPUs it travels while chunk k computes
+        # (its requests sit ahead of chunk k's gather on the communication stream)
+        nxt = begin(starts[0])
+        for k, c0 in enumerate(starts):
+            n, pend = nxt
+            for _local, reqs, _keep in pend:
+                self._p2p_wait(reqs)
+            local_in = [p[0] for p in pend]
+            nxt = begin(starts[k + 1]) if k + 1 < len(starts) else None
             lo, hi = self.bounds(n)
             local_out = compute(local_in, hi - lo)
             outs.append(self.gather(local_out, n, out_shape))
