@@ -517,7 +517,7 @@ def test_config4_full_size_bit_exact():
     g.close(); _ctx_cache.pop((logN, L, K, True), None)
 
 
-@pytest.mark.parametrize("logN,L,K,Li,B", [(13, 6, 2, 5, 3), (14, 4, 4, 2, 2), (15, 3, 1, 3, 1), (13, 9, 3, 9, 2)])
+@pytest.mark.parametrize("logN,L,K,Li,B", [(13, 6, 2, 5, 3), (14, 4, 4, 2, 2), (15, 3, 1, 3, 1), (13, 9, 3, 9, 2), (15, 16, 2, 16, 2)])  # last: BASELINE config 5 shape
 def test_shape_sweep_relin_and_rotate(logN, L, K, Li, B):
     """Ragged shapes at mid sizes: Li < L, odd batches, K != L; multiply+relin+rescale and both rotation variants vs the oracle."""
     o, g = ctx_pair(logN, L, K)
