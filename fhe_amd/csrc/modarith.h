@@ -166,6 +166,37 @@ __device__ __forceinline__ u64 mont_diff(u64 a, u64 b, const PrimeC &P) {
   }
 }
 
+// mont_diff with a wave-uniform first factor (a twiddle that every lane of the workgroup shares, held in scalar registers):
+// its two words go into the multiply-adds as scalar operands, which saves the two per-twiddle copies into vector registers.
+// (One scalar source per instruction: the 2^32 - 1 addend of the first multiply-add therefore sits in a vector pair.)
+__device__ __forceinline__ u64 mont_diff_ua(u64 a_uniform, u64 b, const PrimeC &P) {
+  const u32 a0 = (u32)a_uniform, a1 = (u32)(a_uniform >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  const u32 p1 = P.p1;
+  const u64 k = 0xFFFFFFFFull;
+  u64 t0, t1, t2, d, cc;
+  u32 V2, w1, w2;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(t0), "=s"(cc) : "s"(a0), "v"(b0), "v"(k));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(t1), "=s"(cc) : "s"(a1), "v"(b0), "v"(hi_word(t0)));
+  const u64 m = mad_op(~(u32)t0, p1, t1);
+  asm("v_mad_u64_u32 %0, %2, %3, %4, %5\n\ts_nop 1\n\tv_cndmask_b32_e64 %1, 0, 1, %2"
+      : "=&v"(t2), "=v"(V2), "=&s"(cc)
+      : "s"(a0), "v"(b1), "v"(m));
+  const u32 V0 = (u32)t2, V1 = (u32)(t2 >> 32);
+  const u64 n = mad_op0(V0, p1);
+  const u32 elo = __builtin_subc(V1, (u32)n, 0u, &w1);
+  const u32 ehi = __builtin_subc(V2, (u32)(n >> 32), w1, &w2);
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cc) : "s"(a1), "v"(b1), "v"(pair64(elo, ehi)));
+  return d;
+}
+template <bool SP>
+__device__ __forceinline__ void ct_bfly_ua(u64 &X, u64 &Y, u64 W_uniform, const PrimeC &P) {
+  u64 D;
+  if constexpr (SP) D = mont_diff_ua(W_uniform, Y, P); else D = mont_diff<false>(W_uniform, Y, P);
+  const u64 xp = (X >= P.twop) ? X - P.p : X + P.p;
+  X = xp + D;
+  Y = xp - D;
+}
+
 // a * b * 2^-64 mod p in (0, 2p); a < 2p (Montgomery-form constant or data), b < 4p + 2^32.
 template <bool SP>
 __device__ __forceinline__ u64 mont_mul(u64 a, u64 b, const PrimeC &P) {

@@ -103,6 +103,21 @@ __device__ __forceinline__ void fwd_phase_w(u64 (&e)[1 << LK], const u64 (&w)[(1
   }
 }
 
+// forward phase whose twiddles are the same for every lane (first phase of the column pass: heap indices 1 .. 2^LK - 1)
+template <bool SP, int LK>
+__device__ __forceinline__ void fwd_phase_ua(u64 (&e)[1 << LK], const u64 *__restrict__ tw, const PrimeC &P) {
+#pragma unroll
+  for (int q = 0; q < LK; ++q) {
+    const int half = 1 << (LK - 1 - q);
+#pragma unroll
+    for (int kk = 0; kk < (1 << q); ++kk) {
+      const u64 W = tw[(1 << q) + kk];
+#pragma unroll
+      for (int j = 0; j < half; ++j) ct_bfly_ua<SP>(e[kk * 2 * half + j], e[kk * 2 * half + j + half], W, P);
+    }
+  }
+}
+
 template <bool SP, int LK>
 __device__ __forceinline__ void inv_phase(u64 (&e)[1 << LK], const u64 *__restrict__ tw, u32 base, const PrimeC &P) {
 #pragma unroll
@@ -540,7 +555,7 @@ __global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs
         u64 e[1 << LA];
 #pragma unroll
         for (int k = 0; k < (1 << LA); ++k) e[k] = s[(u64)(g + G * k) * 256 + c];
-        fwd_phase<SP, LA>(e, tw, 1u, P);
+        fwd_phase_ua<SP, LA>(e, tw, P);
 #pragma unroll
         for (int k = 0; k < (1 << LA); ++k) lds[(g + G * k) * CS + c] = e[k];
       }
