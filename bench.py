@@ -32,7 +32,13 @@ WORKLOADS = {
     "c4": (16, 30, 30, 30, 64),
     "ntt": (16, 8, 0, 8, 2048),
     "c2": (14, 8, 0, 8, 8192),
+    # SURVEY 8(f) "next" rows, measured to the same bar (whole-pipeline roofline):
+    "rotm": (16, 30, 1, 30, 16),    # rank 1: MixedRotKey rotation
+    "rotnn": (16, 30, 30, 30, 16),  # rank 2: power-basis rotation (rotate_slots_non_ntt)
+    "dec": (16, 30, 1, 30, 64),     # rank 3: decrypt inner loops
+    "enc": (16, 30, 1, 30, 64),     # rank 3: encrypt inner loops
 }
+GENERIC = ("rotm", "rotnn", "dec", "enc")
 
 
 def gen_primes_host(logN, count):
@@ -79,8 +85,14 @@ def algorithmic_bytes(workload, N, Li, K):
     """SURVEY.md §8(d) per-unit algorithmic bytes (8-byte limbs)."""
     if workload in ("c3", "c5"):
         return 8 * N * (2 * Li * Li + 6 * Li - 2)
-    if workload == "c4":
+    if workload in ("c4", "rotnn"):
         return 8 * N * (6 * Li + 2 * K)
+    if workload == "rotm":  # 2*Li in, 2*Li out, 2*Li*(Li+1) key limbs
+        return 8 * N * (4 * Li + 2 * Li * (Li + 1))
+    if workload == "dec":   # ct (2*Li) + sx (Li) in, Li out
+        return 8 * N * 4 * Li
+    if workload == "enc":   # u, e0+m, e1 (3*Li) + pk (2*Li) in, 2*Li out
+        return 8 * N * 7 * Li
     return 16 * N  # one limb-NTT
 
 
@@ -100,6 +112,15 @@ def cpu_baseline(workload, logN, L, K, Li, inputs, budget_s=20.0):
             t_used += time.perf_counter() - t0
             units += 1
         unit = "ct-mult+relin+rescale/s"
+        sample = "%d op(s) of the bench batch, N=2^%d Li=%d" % (units, logN, Li)
+    elif workload in GENERIC:
+        one_unit = inputs["cpu_one"](o)
+        while t_used < budget_s and units < 4:
+            t0 = time.perf_counter()
+            one_unit(units)
+            t_used += time.perf_counter() - t0
+            units += 1
+        unit = inputs["cpu_unit"]
         sample = "%d op(s) of the bench batch, N=2^%d Li=%d" % (units, logN, Li)
     elif workload == "c4":
         ct, rkb, rka, gal = inputs["ct"], inputs["rkb"], inputs["rka"], inputs["galois"]
@@ -128,6 +149,9 @@ def cpu_baseline(workload, logN, L, K, Li, inputs, budget_s=20.0):
         if workload in ("c3", "c5"):
             one = lambda i: o.mul_relin_rescale(c0[0, 0], c0[0, 1], c1[0, 0], c1[0, 1], beta, alpha)  # noqa: E731
             reps = max(1, int(min(budget_s / 2, 10.0) / per_unit))
+        elif workload in GENERIC:
+            one = one_unit
+            reps = max(1, int(min(budget_s / 2, 10.0) / per_unit))
         elif workload == "c4":
             one = lambda i: o.rotate(ct[0, 0], ct[0, 1], gal, rkb, rka)  # noqa: E731
             reps = max(1, int(min(budget_s / 2, 10.0) / per_unit))
@@ -143,7 +167,7 @@ def cpu_baseline(workload, logN, L, K, Li, inputs, budget_s=20.0):
         with ThreadPoolExecutor(T) as ex:
             list(ex.map(worker, range(T)))
         dt = time.perf_counter() - t0
-        per = 1 if workload in ("c3", "c4", "c5") else nn
+        per = 1 if workload in ("c3", "c4", "c5") + GENERIC else nn
         res["all_cores"] = {"value": T * reps * per / dt, "unit": unit, "cores": T,
                             "sample": "%d thread(s) x %d repetition(s) of one unit each" % (T, reps)}
     except Exception as e:  # the single-thread figure is the contract; this one is extra
@@ -208,6 +232,40 @@ def main():
         work = ct.clone()
         step = lambda: ctx.rotate(galois, work, Li, batch=B)  # noqa: E731
         metric, unit = "rotation-keyswitch/sec at N=2^%d, Li=K=%d" % (logN, Li), "ops/s"
+    elif args.workload in GENERIC:
+        host = lambda t: t.cpu().numpy().view(np.uint64)  # noqa: E731
+        if args.workload in ("rotm", "rotnn"):
+            ct = rnd(B, 2, Li, N)
+            work = ct.clone()
+            galois = 3
+            if args.workload == "rotm":
+                kb, ka = rnd(L, L + 1, N), rnd(L, L + 1, N)
+                ctx.load_mixed_rot_key(galois, kb, ka)
+                step = lambda: ctx.rotate_mixed(galois, work, Li, batch=B)  # noqa: E731
+                metric = "MixedRotKey rotation-keyswitch/sec at N=2^%d, Li=%d" % (logN, Li)
+                inputs["cpu_one"] = lambda o: (lambda i, c=host(ct[:1]), b=host(kb), a=host(ka): o.rotate_mixed(c[0, 0], c[0, 1], galois, b, a))
+            else:
+                kb, ka = rnd(L + K, N), rnd(L + K, N)
+                ctx.load_rot_key(galois, kb, ka)
+                step = lambda: ctx.rotate_non_ntt(galois, work, Li, batch=B)  # noqa: E731
+                metric = "power-basis rotation-keyswitch/sec at N=2^%d, Li=K=%d" % (logN, Li)
+                inputs["cpu_one"] = lambda o: (lambda i, c=host(ct[:1]), b=host(kb), a=host(ka): o.rotate_non_ntt(c[0, 0], c[0, 1], galois, b, a))
+            unit = "ops/s"
+        elif args.workload == "dec":
+            ct, sx = rnd(B, 2, Li, N), rnd(L, N)
+            out = torch.empty((B, Li, N), dtype=torch.int64, device="cuda")
+            step = lambda: ctx.decrypt(out, ct, sx, Li, batch=B)  # noqa: E731
+            metric, unit = "decrypt (bx + sx*ax, INTT)/sec at N=2^%d, Li=%d" % (logN, Li), "ops/s"
+            inputs["cpu_one"] = lambda o: (lambda i, c=host(ct[:1]), s_=host(sx): o.decrypt(c[0, 0], c[0, 1], s_))
+        else:
+            u, e0m, e1 = rnd(B, Li, N), rnd(B, Li, N), rnd(B, Li, N)
+            pkb, pka = rnd(L, N), rnd(L, N)
+            out = torch.empty((B, 2, Li, N), dtype=torch.int64, device="cuda")
+            step = lambda: ctx.encrypt(out, u, e0m, e1, pkb, pka, Li, batch=B)  # noqa: E731
+            metric, unit = "encrypt (NTT, u*pk + e)/sec at N=2^%d, Li=%d" % (logN, Li), "ops/s"
+            inputs["cpu_one"] = lambda o: (lambda i, a_=host(u[:1]), b_=host(e0m[:1]), c_=host(e1[:1]), p_=host(pkb), q_=host(pka):
+                                           o.encrypt_core(a_[0], b_[0], c_[0], p_, q_))
+        inputs["cpu_unit"] = unit
     else:
         x = rnd(B, N)
         idx = np.tile(np.arange(L, dtype=np.uint32), (B + L - 1) // L)[:B]
@@ -220,7 +278,7 @@ def main():
             step = lambda: ctx.ntt_forward(x, idx)  # noqa: E731
             per_step_units = B
         metric, unit = "limb-NTTs/sec at N=2^%d" % logN, "limb-NTT/s"
-    units_per_step = B if args.workload in ("c3", "c4", "c5") else per_step_units
+    units_per_step = B if args.workload in ("c3", "c4", "c5") + GENERIC else per_step_units
 
     def barrier():
         if world > 1:
@@ -267,6 +325,11 @@ def main():
         alg_total = units_per_step * args.steps * 8 * N * (2 * Li * Li + 5 * Li)
         # SURVEY 8(d) also asks for the key-amortised figure: the 2*Li^2 key limbs counted once per launch, not per ciphertext
         alg_amortised = args.steps * 8 * N * (2 * Li * Li + units_per_step * (Li * Li + 5 * Li))
+    elif args.workload in GENERIC:  # the "next" rows: the whole pipeline of the op against its algorithmic bytes
+        launches = args.steps
+        ms = sum(v[1] for v in prof.values())
+        kname = "whole pipeline: " + " + ".join(sorted(prof))
+        alg_total = units_per_step * args.steps * alg
     elif args.workload == "c4":
         launches = kms("bconv_modup")[0] + kms("bconv_moddown")[0]
         ms = kms("bconv_modup")[1] + kms("bconv_moddown")[1]
@@ -309,7 +372,9 @@ def main():
         result["roofline"] = roofline
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        if args.workload in ("c3", "c5"):
+        if args.workload in GENERIC:
+            pass  # inputs["cpu_one"] was set with the workload
+        elif args.workload in ("c3", "c5"):
             nb = min(B, 2)
             inputs.update(c0=c0[:nb].cpu().numpy().view(np.uint64), c1=c1[:nb].cpu().numpy().view(np.uint64),
                           beta=beta.cpu().numpy().view(np.uint64), alpha=alpha.cpu().numpy().view(np.uint64))
