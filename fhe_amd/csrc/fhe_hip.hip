@@ -205,6 +205,7 @@ struct NttPlan {
   const u64 *inv_scale = nullptr;     // inverse only: per-modulus factor replacing N^-1 in the column pass (NttArgs::inv_scale)
   const u32 *perm = nullptr;          // inverse only: gather the source through a galois index table
   const u32 *epi_add_perm = nullptr;  // gather the epilogue addend through a galois index table
+  const u64 *pre_a = nullptr, *pre_k = nullptr;  // inverse, 8-element row pass only: element = src + pre_k * pre_a (NttArgs::pre_a)
 };
 
 template <bool SP, bool INV>
@@ -224,6 +225,12 @@ int launch_cols(fhe_hip_ctx *c, const NttArgs &a, u32 nl, u32 batch) {
   return FHE_HIP_OK;
 }
 
+// the 8-element inverse row kernel (the only one with the fused decrypt load) serves R >= 8 unless switched off
+static bool rows8_inv_in_use(const fhe_hip_ctx *c) {
+  static const bool rows8i = [] { const char *e = getenv("FHE_HIP_ROWS8_INV"); return e ? atoi(e) != 0 : true; }();
+  return rows8i && (1u << c->logR) >= 8;
+}
+
 template <bool SP, bool INV>
 int launch_rows(fhe_hip_ctx *c, const NttArgs &a, u32 nl, u32 batch) {
   const u32 R = 1u << c->logR, rows = R < 16 ? R : 16;
@@ -233,6 +240,7 @@ int launch_rows(fhe_hip_ctx *c, const NttArgs &a, u32 nl, u32 batch) {
       dim3 grid8(R / 8, nl, batch), block8(256);
       if (a.epi == 1) { LAUNCH(c, "ntt_fwd_rows_rescale", (ntt_rows8_fwd_kernel<SP, 1>), grid8, block8, a); return FHE_HIP_OK; }
       if (a.epi == 2) { LAUNCH(c, "ntt_fwd_rows_moddown", (ntt_rows8_fwd_kernel<SP, 2>), grid8, block8, a); return FHE_HIP_OK; }
+      if (a.epi == 3) { LAUNCH(c, "ntt_fwd_rows_encrypt", (ntt_rows8_fwd_kernel<SP, 3>), grid8, block8, a); return FHE_HIP_OK; }
       LAUNCH(c, "ntt_fwd_rows", (ntt_rows8_fwd_kernel<SP, 0>), grid8, block8, a);
       return FHE_HIP_OK;
     }
@@ -248,6 +256,7 @@ int launch_rows(fhe_hip_ctx *c, const NttArgs &a, u32 nl, u32 batch) {
   if constexpr (!INV) {
     if (a.epi == 1) { LAUNCH(c, "ntt_fwd_rows_rescale", (ntt_rows_kernel<SP, false, 1>), grid, block, a); return FHE_HIP_OK; }
     if (a.epi == 2) { LAUNCH(c, "ntt_fwd_rows_moddown", (ntt_rows_kernel<SP, false, 2>), grid, block, a); return FHE_HIP_OK; }
+    if (a.epi == 3) { LAUNCH(c, "ntt_fwd_rows_encrypt", (ntt_rows_kernel<SP, false, 3>), grid, block, a); return FHE_HIP_OK; }
   }
   LAUNCH(c, INV ? "ntt_inv_rows" : "ntt_fwd_rows", (ntt_rows_kernel<SP, INV>), grid, block, a);
   return FHE_HIP_OK;
@@ -263,11 +272,11 @@ int ntt_run_sp(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
   a.dst = p.dst; a.dst_bstride = p.dst_bstride;
   a.epi = inverse ? 0 : p.epi; a.epi_src = p.epi_src; a.epi_c = p.epi_c; a.epi_add = p.epi_add; a.epi_out = p.epi_out;
   a.epi_src_bstride = p.epi_src_bstride; a.epi_add_bstride = p.epi_add_bstride; a.epi_out_bstride = p.epi_out_bstride;
-  a.perm = nullptr; a.epi_add_perm = p.epi_add_perm; a.inv_scale = inverse ? p.inv_scale : nullptr;
+  a.perm = nullptr; a.pre_a = nullptr; a.pre_k = nullptr; a.epi_add_perm = p.epi_add_perm; a.inv_scale = inverse ? p.inv_scale : nullptr;
   // first pass reads the (possibly broadcast) source, second pass runs in place on dst
   NttArgs first = a, second = a;
   first.src = p.src; first.src_bstride = p.src_bstride; first.smod = p.smod;
-  if (inverse) first.perm = p.perm;
+  if (inverse) { first.perm = p.perm; first.pre_a = p.pre_a; first.pre_k = p.pre_k; }
   second.src = p.dst; second.src_bstride = p.dst_bstride; second.smod = p.nl;
   if (!inverse) {
     TRY((launch_cols<SP, false>(c, first, p.nl, p.batch)));
@@ -1127,8 +1136,15 @@ int fhe_hip_decrypt(fhe_hip_ctx *c, uint64_t *out, const uint64_t *ct, const uin
   TRY(st.in(ct, batch * 2 * Li * N * 8, &dct));
   TRY(st.in(sx, (size_t)Li * N * 8, &dsx));
   TRY(st.out(out, batch * Li * N * 8, &dout, false));
-  LAUNCH_SP(c, "decrypt_mac", decrypt_mac_kernel, pw_grid(c, Li, (u32)batch), dim3(PW_THREADS), dout, dct, dsx, (const PrimeC *)c->d_primes, Li, N);
-  TRY(ntt_simple(c, dout, c->d_iota, Li, (u32)batch, (u64)Li * N, true));  // rop->backward(), decryptor.cpp:36
+  if (rows8_inv_in_use(c)) {
+    // bx + sx * ax (decryptor.cpp:24-35) is formed while the inverse row pass loads its rows; rop->backward() (:36) follows
+    NttPlan p{dct, dout, c->d_iota, 1, Li, Li, Li, (u32)batch, (u64)2 * Li * N, (u64)Li * N};
+    p.pre_a = dct + (size_t)Li * N; p.pre_k = dsx;
+    TRY(ntt_run(c, p, true));
+  } else {
+    LAUNCH_SP(c, "decrypt_mac", decrypt_mac_kernel, pw_grid(c, Li, (u32)batch), dim3(PW_THREADS), dout, dct, dsx, (const PrimeC *)c->d_primes, Li, N);
+    TRY(ntt_simple(c, dout, c->d_iota, Li, (u32)batch, (u64)Li * N, true));  // rop->backward(), decryptor.cpp:36
+  }
   return st.finish();
   } catch (...) { return abi_exception(); }
 }
@@ -1142,24 +1158,40 @@ int fhe_hip_encrypt(fhe_hip_ctx *c, uint64_t *ct, const uint64_t *u, const uint6
   if (batch == 0) return FHE_HIP_OK;
   const u64 N = c->N;
   const size_t pb = (size_t)Li * N * 8;
-  // host buffers: 6 inputs + 1 output exceed the staging slots, so the polynomials are staged by hand
+  // The forward NTTs read the sampled polynomials where they lie and write straight into their place ([e][half][Li][N] for
+  // e0+m and e1, a workspace for u): no per-entry copies.  Host buffers (6 inputs + 1 output exceed the staging slots) are
+  // first brought over as they are.
   TRY(ensure_ws(c, 0, batch * pb));
-  TRY(ensure_ws(c, 3, batch * 2 * pb));
   TRY(ensure_ws(c, 4, 2 * pb));
-  u64 *uh = (u64 *)c->ws[0], *dct = mem_kind == FHE_HIP_MEM_DEVICE ? (u64 *)ct : (u64 *)c->ws[3];
-  u64 *dpk = (u64 *)c->ws[4];
-  const hipMemcpyKind in_kind = mem_kind == FHE_HIP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(uh, u, batch * pb, in_kind, c->stream)));
-  for (size_t b = 0; b < batch; ++b) {
-    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(dct + b * 2 * Li * N, e0m + b * Li * N, pb, in_kind, c->stream)));
-    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(dct + (b * 2 + 1) * Li * N, e1 + b * Li * N, pb, in_kind, c->stream)));
+  u64 *uh = (u64 *)c->ws[0], *dpk = (u64 *)c->ws[4];
+  u64 *dct = (u64 *)ct;
+  const u64 *du = (const u64 *)u, *de0 = (const u64 *)e0m, *de1 = (const u64 *)e1, *dpkb = (const u64 *)pk_b, *dpka = (const u64 *)pk_a;
+  if (mem_kind != FHE_HIP_MEM_DEVICE) {
+    TRY(ensure_ws(c, 3, batch * 2 * pb));
+    TRY(ensure_ws(c, 5, batch * 3 * pb));
+    dct = (u64 *)c->ws[3];
+    u64 *in3 = (u64 *)c->ws[5];
+    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(in3, u, batch * pb, hipMemcpyHostToDevice, c->stream)));
+    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(in3 + batch * Li * N, e0m, batch * pb, hipMemcpyHostToDevice, c->stream)));
+    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(in3 + 2 * batch * Li * N, e1, batch * pb, hipMemcpyHostToDevice, c->stream)));
+    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(dpk, pk_b, pb, hipMemcpyHostToDevice, c->stream)));
+    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(dpk + (size_t)Li * N, pk_a, pb, hipMemcpyHostToDevice, c->stream)));
+    du = in3; de0 = in3 + batch * Li * N; de1 = in3 + 2 * batch * Li * N; dpkb = dpk; dpka = dpk + (size_t)Li * N;
   }
-  HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(dpk, pk_b, pb, in_kind, c->stream)));
-  HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(dpk + (size_t)Li * N, pk_a, pb, in_kind, c->stream)));
-  TRY(ntt_simple(c, uh, c->d_iota, Li, (u32)batch, (u64)Li * N, false));           // u.forward(), encryptor.cpp:16
-  TRY(ntt_simple(c, dct, c->d_iota, Li, 2 * (u32)batch, (u64)Li * N, false));     // bx/ax.forward_lazy(), :30,34
-  LAUNCH_SP(c, "encrypt_mac", encrypt_mac_kernel, pw_grid(c, Li, (u32)batch), dim3(PW_THREADS), dct, (const u64 *)uh, (const u64 *)dpk,
-            (const u64 *)(dpk + (size_t)Li * N), (const PrimeC *)c->d_primes, Li, N);
+  {
+    NttPlan pu{du, uh, c->d_iota, 1, Li, Li, Li, (u32)batch, (u64)Li * N, (u64)Li * N};                    // u.forward(), encryptor.cpp:16
+    TRY(ntt_run(c, pu, false));
+    // bx/ax.forward_lazy() (:30,34) with the add_product_of steps (:31,35) as the epilogue of the row pass: the column
+    // pass writes into the half's own place, the row pass reads it there and overwrites it with NTT(e) + u^ * pk
+    NttPlan p0{de0, dct, c->d_iota, 1, Li, Li, Li, (u32)batch, (u64)Li * N, (u64)2 * Li * N};
+    p0.epi = 3; p0.epi_src = uh; p0.epi_src_bstride = (u64)Li * N; p0.epi_add = dpkb; p0.epi_add_bstride = 0;
+    p0.epi_out = dct; p0.epi_out_bstride = (u64)2 * Li * N;
+    TRY(ntt_run(c, p0, false));
+    NttPlan p1{de1, dct + (size_t)Li * N, c->d_iota, 1, Li, Li, Li, (u32)batch, (u64)Li * N, (u64)2 * Li * N};
+    p1.epi = 3; p1.epi_src = uh; p1.epi_src_bstride = (u64)Li * N; p1.epi_add = dpka; p1.epi_add_bstride = 0;
+    p1.epi_out = dct + (size_t)Li * N; p1.epi_out_bstride = (u64)2 * Li * N;
+    TRY(ntt_run(c, p1, false));
+  }
   if (mem_kind != FHE_HIP_MEM_DEVICE) {
     HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(ct, dct, batch * 2 * pb, hipMemcpyDeviceToHost, c->stream)));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -33,6 +33,9 @@ struct NttArgs {
   const u64 *inv_scale;  // inverse column pass only: [M] Montgomery-form factors used instead of N^-1 (N^-1 times a constant the consumer needs)
   const u32 *perm;   // inverse row pass only: element d of a limb is read from src[perm[d]] (fHE::apply_galois fused into the load)
   const u32 *epi_add_perm;  // same for the epilogue addend
+  // inverse row pass only (8-element kernel): the element read is src + pre_k * pre_a  (Decryptor::decrypt, decryptor.cpp:24-35:
+  // bx + sx * ax); pre_a = [b](src_bstride)[limb][N] like src, pre_k = [limb][N]; null = plain load
+  const u64 *pre_a, *pre_k;
   u32 epi;
   const u64 *epi_src, *epi_c, *epi_add;
   u64 *epi_out;
@@ -198,9 +201,15 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
       } else {
         const u64 off = (u64)l * N + (u64)row * 256 + 32 * i + 2 * t;
         const ulonglong2 h = *reinterpret_cast<const ulonglong2 *>(&a.epi_src[(u64)b * a.epi_src_bstride + off]);
-        const u64 cm = a.epi_c[m];
         u64 r0, r1;
-        if constexpr (EPI == 1) {
+        [[maybe_unused]] u64 cm = 0;
+        if constexpr (EPI != 3) cm = a.epi_c[m];
+        if constexpr (EPI == 3) {
+          // Encryptor::encrypt add_product_of (src/encryptor.cpp:31,35): out = NTT(e) + u^ * pk, u^ = epi_src, pk = epi_add
+          const ulonglong2 pk = *reinterpret_cast<const ulonglong2 *>(&a.epi_add[(u64)b * a.epi_add_bstride + off]);
+          r0 = csub(mulmod_full<SP>(pk.x, h.x, P) + csub(v.x, P.p), P.p);
+          r1 = csub(mulmod_full<SP>(pk.y, h.y, P) + csub(v.y, P.p), P.p);
+        } else if constexpr (EPI == 1) {
           r0 = csub(mont_mul<SP>(cm, h.x + P.twop - v.x, P), P.p);
           r1 = csub(mont_mul<SP>(cm, h.y + P.twop - v.y, P), P.p);
         } else {
@@ -328,9 +337,15 @@ __global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
     } else {
       const u64 off = (u64)l * N + (u64)row * 256 + el;
       const ulonglong2 h = *reinterpret_cast<const ulonglong2 *>(&a.epi_src[(u64)b * a.epi_src_bstride + off]);
-      const u64 cm = a.epi_c[m];
       u64 r0, r1;
-      if constexpr (EPI == 1) {
+      [[maybe_unused]] u64 cm = 0;
+      if constexpr (EPI != 3) cm = a.epi_c[m];
+      if constexpr (EPI == 3) {
+        // Encryptor::encrypt add_product_of (src/encryptor.cpp:31,35): out = NTT(e) + u^ * pk, u^ = epi_src, pk = epi_add
+        const ulonglong2 pk = *reinterpret_cast<const ulonglong2 *>(&a.epi_add[(u64)b * a.epi_add_bstride + off]);
+        r0 = csub(mulmod_full<SP>(pk.x, h.x, P) + csub(v.x, P.p), P.p);
+        r1 = csub(mulmod_full<SP>(pk.y, h.y, P) + csub(v.y, P.p), P.p);
+      } else if constexpr (EPI == 1) {
         r0 = csub(mont_mul<SP>(cm, h.x + P.twop - v.x, P), P.p);
         r1 = csub(mont_mul<SP>(cm, h.y + P.twop - v.y, P), P.p);
       } else {
@@ -380,6 +395,13 @@ __global__ __launch_bounds__(256) void ntt_rows8_inv_kernel(NttArgs a) {
       v = make_ulonglong2(sl[pi.x], sl[pi.y]);
     } else {
       v = *reinterpret_cast<const ulonglong2 *>(&s[el]);
+    }
+    if (a.pre_a) {
+      const u64 lo = (u64)(l % a.smod) * N + (u64)row * 256 + el;
+      const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(&a.pre_a[(u64)b * a.src_bstride + lo]);
+      const ulonglong2 k = *reinterpret_cast<const ulonglong2 *>(&a.pre_k[lo]);
+      v.x = csub(mulmod_full<SP>(k.x, x.x, P) + csub(v.x, P.p), P.p);
+      v.y = csub(mulmod_full<SP>(k.y, x.y, P) + csub(v.y, P.p), P.p);
     }
     *reinterpret_cast<ulonglong2 *>(&L[row8_pos(el)]) = v;
   }

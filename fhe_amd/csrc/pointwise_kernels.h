@@ -249,17 +249,3 @@ __global__ __launch_bounds__(PW_THREADS) void decrypt_mac_kernel(u64 *out, const
       addmod_c(mulmod_full<SP>(s.y, a.y, P), csub(b.y, P.p), P.p));
 }
 
-// Encryptor::encrypt add_product_of steps (src/encryptor.cpp:31,35): ct[e][0][l] = e0m^ + u^*pk_b, ct[e][1][l] = e1^ + u^*pk_a
-// uh / ct halves hold the forward NTTs already; ct = [e][2][Li][N] in place, uh = [e][Li][N]
-template <bool SP>
-__global__ __launch_bounds__(PW_THREADS) void encrypt_mac_kernel(u64 *ct, const u64 *uh, const u64 *pk_b, const u64 *pk_a,
-                                                                 const PrimeC *primes, u32 Li, u64 N) {
-  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
-  const u32 l = blockIdx.y, e = blockIdx.z;
-  const PrimeC P = primes[l];
-  const u64 o = ((u64)e * 2 * Li + l) * N + d, half = (u64)Li * N;
-  const ulonglong2 u = ld2(uh + ((u64)e * Li + l) * N + d), b = ld2(ct + o), a = ld2(ct + o + half);
-  const ulonglong2 kb = ld2(pk_b + (u64)l * N + d), ka = ld2(pk_a + (u64)l * N + d);
-  st2(ct + o, addmod_c(mulmod_full<SP>(kb.x, u.x, P), b.x, P.p), addmod_c(mulmod_full<SP>(kb.y, u.y, P), b.y, P.p));
-  st2(ct + o + half, addmod_c(mulmod_full<SP>(ka.x, u.x, P), a.x, P.p), addmod_c(mulmod_full<SP>(ka.y, u.y, P), a.y, P.p));
-}

@@ -382,11 +382,12 @@ def test_add_and_multiply_plain():
     assert np.array_equal(host(d), want)
 
 
-@pytest.mark.parametrize("Li", [4, 2])
-def test_encrypt_decrypt_inner_loops_on_device(Li):
-    """encryptor.cpp:15-35 / decryptor.cpp:24-36 on the device, sampled polynomials from the host."""
-    logN, L, K = 11, 4, 1
-    o, g = ctx_pair(logN, L, K)
+@pytest.mark.parametrize("Li,logN,sp", [(4, 11, True), (2, 11, True), (3, 10, True), (3, 12, False)])
+def test_encrypt_decrypt_inner_loops_on_device(Li, logN, sp):
+    """encryptor.cpp:15-35 / decryptor.cpp:24-36 on the device, sampled polynomials from the host.
+    (logN = 10 takes the 16-element row kernels, sp = False the generic-prime instantiations.)"""
+    L, K = 4, 1
+    o, g = ctx_pair(logN, L, K, sp)
     sx, ext = o.keygen_sk(seed=140)
     pkb, pka = o.keygen_pk(sx, seed=141)
     B = 2
