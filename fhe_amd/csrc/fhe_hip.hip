@@ -225,6 +225,13 @@ int launch_cols(fhe_hip_ctx *c, const NttArgs &a, u32 nl, u32 batch) {
   return FHE_HIP_OK;
 }
 
+// g^-1 mod 2N for odd g (Newton iteration mod 2^64, then masked)
+static u64 galois_inverse(u64 g, u64 N) {
+  u64 inv = g;
+  for (int i = 0; i < 6; ++i) inv *= 2 - g * inv;
+  return inv & (2 * N - 1);
+}
+
 // the 8-element inverse row kernel (the only one with the fused decrypt load) serves R >= 8 unless switched off
 static bool rows8_inv_in_use(const fhe_hip_ctx *c) {
   static const bool rows8i = [] { const char *e = getenv("FHE_HIP_ROWS8_INV"); return e ? atoi(e) != 0 : true; }();
@@ -509,7 +516,7 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
     HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(g, ct, ctb, hipMemcpyDeviceToDevice, c->stream)));
   } else if (non_ntt) {
     LAUNCH(c, "galois_coeff", galois_coeff_kernel, dim3((unsigned)(N / PW_THREADS), 2 * Li, batch), dim3(PW_THREADS), g, (const u64 *)ct,
-           (const PrimeC *)c->d_primes, c->logN, galois, Li);
+           (const PrimeC *)c->d_primes, c->logN, galois_inverse(galois, c->N), Li);
   } else {
     TRY(get_galois_perm(c, galois, &perm));
     LAUNCH(c, "galois_gather", galois_gather_kernel, dim3((unsigned)(N / PW_THREADS), Li, batch), dim3(PW_THREADS), g, (const u64 *)ct,
@@ -806,7 +813,7 @@ static int galois_api(fhe_hip_ctx *c, uint64_t *polys, uint32_t nlimbs, uint64_t
     LAUNCH(c, "galois_gather", galois_gather_kernel, grid, dim3(PW_THREADS), d, (const u64 *)tmp, (const u32 *)perm, c->N, (u64)nlimbs * c->N,
            (u64)nlimbs * c->N);
   } else {
-    LAUNCH(c, "galois_coeff", galois_coeff_kernel, grid, dim3(PW_THREADS), d, (const u64 *)tmp, (const PrimeC *)c->d_primes, c->logN, galois, nlimbs);
+    LAUNCH(c, "galois_coeff", galois_coeff_kernel, grid, dim3(PW_THREADS), d, (const u64 *)tmp, (const PrimeC *)c->d_primes, c->logN, galois_inverse(galois, c->N), nlimbs);
   }
   return st.finish();
   } catch (...) { return abi_exception(); }

@@ -183,17 +183,19 @@ __global__ void galois_perm_kernel(u32 *perm, u32 logN, u64 galois) {
   const u64 raw = (galois * (2ull * r + 1)) & (2ull * N - 1);
   perm[d] = __brev((u32)((raw - 1) >> 1)) >> (32 - logN);
 }
-// fHE::apply_galois_non_ntt (src/yell.cpp:41-52): scatter with sign flip; limb k uses modulus k; out-of-place.
+// fHE::apply_galois_non_ntt (src/yell.cpp:41-52): tmp[(d*g) mod N] = +-t_d with the sign flipped when (d*g) mod 2N >= N.  Run as a
+// gather so that the stores are coalesced: output j comes from d' = j * g^-1 mod 2N (g odd): d' < N -> +src[d'], else -src[d' - N]
+// (then (d' - N) * g = j + N mod 2N).  Limb k uses modulus k % mper; out-of-place.  ginv = g^-1 mod 2N.
 __global__ __launch_bounds__(PW_THREADS) void galois_coeff_kernel(u64 *dst, const u64 *src, const PrimeC *primes, u32 logN,
-                                                                  u64 galois, u32 mper) {
+                                                                  u64 ginv, u32 mper) {
   const u64 N = 1ull << logN;
-  const u64 d = (u64)blockIdx.x * PW_THREADS + threadIdx.x;
+  const u64 j = (u64)blockIdx.x * PW_THREADS + threadIdx.x;
   const u32 cm = blockIdx.y;
   const u64 o = ((u64)blockIdx.z * gridDim.y + cm) * N;
-  const u64 raw = d * galois;
-  const u64 t = src[o + d];
+  const u64 dp = (j * ginv) & (2 * N - 1);
+  const u64 t = src[o + (dp & (N - 1))];
   const u64 p = primes[cm % mper].p;  // limb cm of a [..][mper][N] stack lives under prime cm % mper
-  dst[o + (raw & (N - 1))] = ((raw >> logN) & 1) ? (t > 0 ? p - t : 0) : t;
+  dst[o + j] = (dp >> logN) ? (t > 0 ? p - t : 0) : t;
 }
 
 // rop[e][l] += op[e][l] with separate batch strides (elements): "rop[0] = ct[0] + ..." of evaluator.cpp:503-514
