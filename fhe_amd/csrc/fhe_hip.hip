@@ -634,15 +634,18 @@ int dev_rotate_mixed(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch) {
   // rescale by the special prime (:475-515): entries = 2*batch polys of Li+1 limbs, last limb lives under P[L]
   NttPlan pl{ans + (size_t)Li * N, ans + (size_t)Li * N, c->d_iota + c->L, 1, 1, 1, 1, 2 * batch, (u64)nout * N, (u64)nout * N};
   TRY(ntt_run(c, pl, true));
-  TRY(ensure_ws(c, 2, (size_t)2 * batch * Li * N * 8));
+  // per half: tail_j = NTT_j(last limb) for j < Li with the rescale arithmetic (:485-515) as the epilogue of the row pass,
+  // rop_j = (ans_j - tail_j) * P[L]^-1; the bx half also takes "+ galois(ct[0])" (:503-514) there.  Nothing is re-read.
+  TRY(ensure_ws(c, 2, (size_t)batch * Li * N * 8));
   u64 *tail = (u64 *)c->ws[2];
-  NttPlan ptl{ans + (size_t)Li * N, tail, c->d_iota, 1, Li, 1, Li, 2 * batch, (u64)nout * N, (u64)Li * N};
-  TRY(ntt_run(c, ptl, false));
-  LAUNCH_SP(c, "rescale", rescale_kernel, pw_grid(c, Li, 2 * batch), dim3(PW_THREADS), ct, (const u64 *)ans, (const u64 *)tail,
-            (const u64 *)(c->d_qinv_m + (size_t)c->L * c->M), (const PrimeC *)c->d_primes, nout, N);
-  // rop[0] = ct[0] + ... (:503-514): add galois(bx) onto the bx halves
-  LAUNCH(c, "add_strided", add_strided_kernel, pw_grid(c, Li, batch), dim3(PW_THREADS), ct, (const u64 *)g, (const PrimeC *)c->d_primes, N,
-         (u64)2 * Li * N, (u64)2 * Li * N);
+  for (u32 h = 0; h < 2; ++h) {
+    const u64 *half = ans + (size_t)h * nout * N;
+    NttPlan ptl{half + (size_t)Li * N, tail, c->d_iota, 1, Li, 1, Li, batch, (u64)2 * nout * N, (u64)Li * N};
+    ptl.epi = 1; ptl.epi_src = half; ptl.epi_src_bstride = (u64)2 * nout * N; ptl.epi_c = c->d_qinv_m + (size_t)c->L * c->M;
+    ptl.epi_out = ct + (size_t)h * Li * N; ptl.epi_out_bstride = (u64)2 * Li * N;
+    if (h == 0) { ptl.epi_add = g; ptl.epi_add_bstride = (u64)2 * Li * N; }
+    TRY(ntt_run(c, ptl, false));
+  }
   return FHE_HIP_OK;
 }
 

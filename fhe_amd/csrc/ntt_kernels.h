@@ -212,6 +212,10 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
         } else if constexpr (EPI == 1) {
           r0 = csub(mont_mul<SP>(cm, h.x + P.twop - v.x, P), P.p);
           r1 = csub(mont_mul<SP>(cm, h.y + P.twop - v.y, P), P.p);
+          if (a.epi_add) {  // MixedRotKey tail: rop[0] = ct[0] + ... (src/evaluator.cpp:503-514)
+            const ulonglong2 ad = *reinterpret_cast<const ulonglong2 *>(&a.epi_add[(u64)b * a.epi_add_bstride + off]);
+            r0 = csub(r0 + ad.x, P.p); r1 = csub(r1 + ad.y, P.p);
+          }
         } else {
           r0 = csub(mont_mul<SP>(cm, h.x + v.x, P), P.p);
           r1 = csub(mont_mul<SP>(cm, h.y + v.y, P), P.p);
@@ -348,6 +352,10 @@ __global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
       } else if constexpr (EPI == 1) {
         r0 = csub(mont_mul<SP>(cm, h.x + P.twop - v.x, P), P.p);
         r1 = csub(mont_mul<SP>(cm, h.y + P.twop - v.y, P), P.p);
+        if (a.epi_add) {  // MixedRotKey tail: rop[0] = ct[0] + ... (src/evaluator.cpp:503-514)
+          const ulonglong2 ad = *reinterpret_cast<const ulonglong2 *>(&a.epi_add[(u64)b * a.epi_add_bstride + off]);
+          r0 = csub(r0 + ad.x, P.p); r1 = csub(r1 + ad.y, P.p);
+        }
       } else {
         r0 = csub(mont_mul<SP>(cm, h.x + v.x, P), P.p);
         r1 = csub(mont_mul<SP>(cm, h.y + v.y, P), P.p);

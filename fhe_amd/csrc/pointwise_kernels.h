@@ -38,21 +38,6 @@ __global__ __launch_bounds__(PW_THREADS) void cross_mult_kernel(u64 *out3, const
   st2(out3 + o + 2 * half, r2[0], r2[1]);
 }
 
-// BaseConverter::rescale inner loop (src/base_converter.cpp:264-271): out_j = (head_j + q_j - tail_j) * q_last^-1 mod q_j
-// head = [e][n][N] (limbs j < n-1 used), tail = [e][n-1][N], out = [e][n-1][N]; qinv_m = row (n-1) of the
-// (P[a]^-1 mod P[j]) table in Montgomery form.
-template <bool SP>
-__global__ __launch_bounds__(PW_THREADS) void rescale_kernel(u64 *out, const u64 *head, const u64 *tail, const u64 *qinv_m,
-                                                             const PrimeC *primes, u32 n, u64 N) {
-  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
-  const u32 j = blockIdx.y, e = blockIdx.z;
-  const PrimeC P = primes[j];
-  const u64 qi = qinv_m[j];
-  const ulonglong2 h = ld2(head + ((u64)e * n + j) * N + d), tl = ld2(tail + ((u64)e * (n - 1) + j) * N + d);
-  st2(out + ((u64)e * (n - 1) + j) * N + d, csub(mont_mul<SP>(qi, h.x + P.p - tl.x, P), P.p),
-      csub(mont_mul<SP>(qi, h.y + P.p - tl.y, P), P.p));
-}
-
 // internal::do_approximated_basis_conversion (src/base_converter.cpp:313-349), all targets of one
 // conversion: out[t][d] = ( sum_k [x_k[d] * inv_k]_{src_k} * hat[t][k] ) mod tgt_t   (uncorrected).
 // src = [e][src_limbs][N] (limbs src_off .. src_off+nsrc), out = [e][out_limbs][N] (limbs out_off + t).
@@ -196,16 +181,6 @@ __global__ __launch_bounds__(PW_THREADS) void galois_coeff_kernel(u64 *dst, cons
   const u64 t = src[o + (dp & (N - 1))];
   const u64 p = primes[cm % mper].p;  // limb cm of a [..][mper][N] stack lives under prime cm % mper
   dst[o + j] = (dp >> logN) ? (t > 0 ? p - t : 0) : t;
-}
-
-// rop[e][l] += op[e][l] with separate batch strides (elements): "rop[0] = ct[0] + ..." of evaluator.cpp:503-514
-__global__ __launch_bounds__(PW_THREADS) void add_strided_kernel(u64 *rop, const u64 *op, const PrimeC *primes, u64 N, u64 rop_bstride,
-                                                                 u64 op_bstride) {
-  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
-  const u64 p = primes[blockIdx.y].p;
-  u64 *r = rop + (u64)blockIdx.z * rop_bstride + (u64)blockIdx.y * N + d;
-  const ulonglong2 a = ld2(r), b = ld2(op + (u64)blockIdx.z * op_bstride + (u64)blockIdx.y * N + d);
-  st2(r, addmod_c(a.x, b.x, p), addmod_c(a.y, b.y, p));
 }
 
 // poly operator+= (src/evaluator.cpp:284-285): rop, op = [e][nl][N], limb k uses modulus k
