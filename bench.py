@@ -8,6 +8,9 @@ A "step" is one pass of the hot path over one batch of synthetic, HBM-resident i
   --workload c2  N=2^14, 8 limbs x 1024 polys forward+inverse NTT
   --workload c4  N=2^16, Li=K=30 rotation key switch
   --workload c5  N=2^15, Li=16 multiply+relin+rescale
+  --workload rotm | rotnn | dec | enc   the SURVEY 8(f) rows: MixedRotKey rotation, power-basis rotation, decrypt and encrypt
+                 inner loops (N=2^16, Li=30); their `roofline` is the whole pipeline against the op's algorithmic bytes
+Before the W warmup steps the steps run untimed for --prewarm seconds (clock ramp).
 One rank per GPU (torch.distributed / RCCL is used only for the barrier and the max-over-ranks of the time:
 independent ciphertexts shard with no data-path collective -> "scaling": "weak").
 Rank 0 prints ONE JSON line.
