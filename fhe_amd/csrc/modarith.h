@@ -97,12 +97,6 @@ __device__ __forceinline__ u64 mad_op_k(u32 a, u32 b) {
   asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cc) : "v"(a), "v"(b), "s"(k));
   return d;
 }
-// x >> 32 as one 64-bit shift (the compiler's own lowering moves the word and zeroes the other: two instructions)
-__device__ __forceinline__ u64 hi_word(u64 x) {
-  u64 d;
-  asm("v_lshrrev_b64 %0, 32, %1" : "=v"(d) : "v"(x));
-  return d;
-}
 
 // Reference formulation of mont_diff (kept for tools/ubench/bfly.hip and the generic-prime path).
 template <bool SP>
@@ -152,7 +146,7 @@ __device__ __forceinline__ u64 mont_diff(u64 a, u64 b, const PrimeC &P) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u32 p1 = P.p1;
     const u64 t0 = mad_op_k(a0, b0);                      // a0*b0 + 2^32 - 1 <= 2^64 - 2^32: (T0 - 1, h0 + c0)
-    const u64 t1 = mad_op(a1, b0, hi_word(t0));           // < 2^62 + 2^32
+    const u64 t1 = mad_op(a1, b0, t0 >> 32);              // < 2^62 + 2^32 (a move and a shared zero: cheaper than a 64-bit shift)
     const u64 m = mad_op(~(u32)t0, p1, t1);               // q0 = -T0 = ~(T0 - 1);  < 2^63 + 2^32
     u32 V2, w1, w2;
     const u64 t2 = mad_op_carry(a0, b1, m, V2);
@@ -176,7 +170,7 @@ __device__ __forceinline__ u64 mont_diff_ua(u64 a_uniform, u64 b, const PrimeC &
   u64 t0, t1, t2, d, cc;
   u32 V2, w1, w2;
   asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(t0), "=s"(cc) : "s"(a0), "v"(b0), "v"(k));
-  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(t1), "=s"(cc) : "s"(a1), "v"(b0), "v"(hi_word(t0)));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(t1), "=s"(cc) : "s"(a1), "v"(b0), "v"(t0 >> 32));
   const u64 m = mad_op(~(u32)t0, p1, t1);
   asm("v_mad_u64_u32 %0, %2, %3, %4, %5\n\ts_nop 1\n\tv_cndmask_b32_e64 %1, 0, 1, %2"
       : "=&v"(t2), "=v"(V2), "=&s"(cc)

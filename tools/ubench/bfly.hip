@@ -9,7 +9,7 @@
   fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
 
 #ifndef VARIANTS
-#define VARIANTS 4
+#define VARIANTS 6
 #endif
 
 template <int V> __device__ __forceinline__ void bf(u64 &X, u64 &Y, u64 W, const PrimeC &P);
@@ -65,6 +65,54 @@ template <> __device__ __forceinline__ void bf<3>(u64 &X, u64 &Y, u64 W, const P
   Y = xp - D;
 }
 
+// variant 4 = variant 1 with compiler-generated multiply-adds kept in order by empty asm statements (no inline-asm hazard
+// padding after each multiply-add; the carry multiply-add stays an asm block)
+__device__ __forceinline__ void keep(u64 &x) { asm("" : "+v"(x)); }
+__device__ __forceinline__ u64 mont_diff_v4(u64 a, u64 b, const PrimeC &P) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  const u32 p1 = P.p1;
+  u64 t0 = (u64)a0 * b0 + 0xFFFFFFFFull; keep(t0);
+  u64 t1 = (u64)a1 * b0 + (t0 >> 32); keep(t1);
+  u64 m = (u64)(~(u32)t0) * p1 + t1; keep(m);
+  u32 V2, w1, w2;
+  const u64 t2 = mad_op_carry(a0, b1, m, V2);
+  const u32 V0 = (u32)t2, V1 = (u32)(t2 >> 32);
+  u64 n = (u64)V0 * p1; keep(n);
+  const u32 elo = __builtin_subc(V1, (u32)n, 0u, &w1);
+  const u32 ehi = __builtin_subc(V2, (u32)(n >> 32), w1, &w2);
+  u64 e = pair64(elo, ehi); keep(e);
+  u64 d = (u64)a1 * b1 + e; keep(d);
+  return d;
+}
+template <> __device__ __forceinline__ void bf<4>(u64 &X, u64 &Y, u64 W, const PrimeC &P) {
+  const u64 D = mont_diff_v4(W, Y, P);
+  const u64 xp = (X >= P.twop) ? X - P.p : X + P.p;
+  X = xp + D;
+  Y = xp - D;
+}
+
+// variant 5 = variant 1 with the high word brought down by the compiler's own lowering of t0 >> 32 (a move plus a zero)
+__device__ __forceinline__ u64 mont_diff_v5(u64 a, u64 b, const PrimeC &P) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  const u32 p1 = P.p1;
+  const u64 t0 = mad_op_k(a0, b0);
+  const u64 t1 = mad_op(a1, b0, t0 >> 32);
+  const u64 m = mad_op(~(u32)t0, p1, t1);
+  u32 V2, w1, w2;
+  const u64 t2 = mad_op_carry(a0, b1, m, V2);
+  const u32 V0 = (u32)t2, V1 = (u32)(t2 >> 32);
+  const u64 n = mad_op0(V0, p1);
+  const u32 elo = __builtin_subc(V1, (u32)n, 0u, &w1);
+  const u32 ehi = __builtin_subc(V2, (u32)(n >> 32), w1, &w2);
+  return mad_op(a1, b1, pair64(elo, ehi));
+}
+template <> __device__ __forceinline__ void bf<5>(u64 &X, u64 &Y, u64 W, const PrimeC &P) {
+  const u64 D = mont_diff_v5(W, Y, P);
+  const u64 xp = (X >= P.twop) ? X - P.p : X + P.p;
+  X = xp + D;
+  Y = xp - D;
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void k(u64 *d, const u64 *w, PrimeC P, int iters) {
   u64 x[16], tw[15];
@@ -112,7 +160,9 @@ int main() {
       if (v == 0) k<0><<<nblk, 256>>>(d[v], dw, P, iters);
       else if (v == 1) k<1><<<nblk, 256>>>(d[v], dw, P, iters);
       else if (v == 2) k<2><<<nblk, 256>>>(d[v], dw, P, iters);
-      else k<3><<<nblk, 256>>>(d[v], dw, P, iters);
+      else if (v == 3) k<3><<<nblk, 256>>>(d[v], dw, P, iters);
+      else if (v == 4) k<4><<<nblk, 256>>>(d[v], dw, P, iters);
+      else k<5><<<nblk, 256>>>(d[v], dw, P, iters);
       CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
       float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
       const double bf = (double)nblk * 256 * 32 * iters;
