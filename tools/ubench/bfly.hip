@@ -9,7 +9,7 @@
   fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
 
 #ifndef VARIANTS
-#define VARIANTS 6
+#define VARIANTS 7
 #endif
 
 template <int V> __device__ __forceinline__ void bf(u64 &X, u64 &Y, u64 W, const PrimeC &P);
@@ -113,6 +113,20 @@ template <> __device__ __forceinline__ void bf<5>(u64 &X, u64 &Y, u64 W, const P
   Y = xp - D;
 }
 
+// variant 6 = variant 5 with the 2p reduction of X decided on the high word by plain 32-bit operations
+// (values then live in [0, 4p + 2^32))
+__device__ __forceinline__ u64 xp_fast(u64 X, const PrimeC &P) {
+  const int dd = (int)(2u * P.p1 - (u32)(X >> 32));  // < 0  <=>  X.hi > 2*p1  =>  subtract p, else add p
+  const u32 mask = (u32)(dd >> 31);
+  return X + pair64(mask | 1u, P.p1 ^ mask);
+}
+template <> __device__ __forceinline__ void bf<6>(u64 &X, u64 &Y, u64 W, const PrimeC &P) {
+  const u64 D = mont_diff_v5(W, Y, P);
+  const u64 xp = xp_fast(X, P);
+  X = xp + D;
+  Y = xp - D;
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void k(u64 *d, const u64 *w, PrimeC P, int iters) {
   u64 x[16], tw[15];
@@ -162,7 +176,8 @@ int main() {
       else if (v == 2) k<2><<<nblk, 256>>>(d[v], dw, P, iters);
       else if (v == 3) k<3><<<nblk, 256>>>(d[v], dw, P, iters);
       else if (v == 4) k<4><<<nblk, 256>>>(d[v], dw, P, iters);
-      else k<5><<<nblk, 256>>>(d[v], dw, P, iters);
+      else if (v == 5) k<5><<<nblk, 256>>>(d[v], dw, P, iters);
+      else k<6><<<nblk, 256>>>(d[v], dw, P, iters);
       CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
       float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
       const double bf = (double)nblk * 256 * 32 * iters;
