@@ -100,7 +100,7 @@ class Oracle:
         self.h = lib.orc_ctx_create(logN, L, K, _p(self.primes), _p(self.psi))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:  # lib is already gone at interpreter shutdown
             lib.orc_ctx_destroy(self.h)
             self.h = None
 
