@@ -1,4 +1,5 @@
-"""Randomised soak of the C-ABI against the CPU oracle (small sizes, many shapes): tools/gpu_soak.py [seconds] [seed].
+"""Randomised soak of the C-ABI against the CPU oracle (many shapes): tools/gpu_soak.py [seconds] [seed] [logN_lo] [logN_hi] [generic].
+`generic` = 1 alternates the repository's prime table with primes that are not 1 mod 2^32 (generic Montgomery kernels).
 Not part of the test suite (run time); every mismatch prints the configuration and exits non-zero."""
 import sys, time
 import numpy as np
@@ -11,16 +12,37 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
 host = lambda t: t.cpu().numpy().view(np.uint64)
+lo = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+hi = int(sys.argv[4]) if len(sys.argv) > 4 else 13
+generic = len(sys.argv) > 5 and sys.argv[5] == "1"
+
+
+def generic_primes(logN, count):
+    pr, ps = [], []
+    step = 1 << (logN + 1)
+    p = (1 << 61) + (1 << 60) + 1
+    p -= (p - 1) % step
+    while len(pr) < count:
+        p -= step
+        if p % (1 << 32) != 1 and orc.lib.orc_is_prime(p):
+            x = 2
+            while pow(x, (p - 1) // 2, p) != p - 1:
+                x += 1
+            pr.append(p)
+            ps.append(pow(x, (p - 1) >> (logN + 1), p))
+    return np.array(pr, np.uint64), np.array(ps, np.uint64)
+
+
 t_end = time.time() + budget
 n_cfg = n_chk = 0
 while time.time() < t_end:
-    logN = int(rng.integers(10, 14))
+    logN = int(rng.integers(lo, hi + 1))
     L = int(rng.integers(2, 9)); K = int(rng.integers(1, L + 2)); Li = int(rng.integers(2, L + 1)); B = int(rng.integers(1, 4))
-    pr, ps = orc.gen_primes(logN, L + K)
+    pr, ps = generic_primes(logN, L + K) if (generic and n_cfg % 2) else orc.gen_primes(logN, L + K)
     o = orc.Oracle(logN, L, K, pr, ps)
     g = fhe_amd.HipContext(logN, L, K, pr, ps)
     N = o.N
-    cfg = dict(logN=logN, L=L, K=K, Li=Li, B=B)
+    cfg = dict(logN=logN, L=L, K=K, Li=Li, B=B, generic=bool(generic and n_cfg % 2))
     def uni(idx):
         return np.stack([rng.integers(0, int(o.primes[i]), N, dtype=np.uint64) for i in idx])
     def check(name, got, want):
