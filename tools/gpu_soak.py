@@ -1,4 +1,4 @@
-"""Randomised soak of the C-ABI against the CPU oracle (many shapes): tools/gpu_soak.py [seconds] [seed] [logN_lo] [logN_hi] [generic].
+"""Randomised soak of the C-ABI against the CPU oracle (many shapes): tools/gpu_soak.py [seconds] [seed] [logN_lo] [logN_hi] [generic] [Lmax].
 `generic` = 1 alternates the repository's prime table with primes that are not 1 mod 2^32 (generic Montgomery kernels).
 Not part of the test suite (run time); every mismatch prints the configuration and exits non-zero."""
 import sys, time
@@ -15,6 +15,7 @@ host = lambda t: t.cpu().numpy().view(np.uint64)
 lo = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 hi = int(sys.argv[4]) if len(sys.argv) > 4 else 13
 generic = len(sys.argv) > 5 and sys.argv[5] == "1"
+Lmax = int(sys.argv[6]) if len(sys.argv) > 6 else 8
 
 
 def generic_primes(logN, count):
@@ -37,7 +38,7 @@ t_end = time.time() + budget
 n_cfg = n_chk = 0
 while time.time() < t_end:
     logN = int(rng.integers(lo, hi + 1))
-    L = int(rng.integers(2, 9)); K = int(rng.integers(1, L + 2)); Li = int(rng.integers(2, L + 1)); B = int(rng.integers(1, 4))
+    L = int(rng.integers(2, Lmax + 1)); K = int(rng.integers(1, L + 2)); Li = int(rng.integers(2, L + 1)); B = int(rng.integers(1, 4))
     pr, ps = generic_primes(logN, L + K) if (generic and n_cfg % 2) else orc.gen_primes(logN, L + K)
     o = orc.Oracle(logN, L, K, pr, ps)
     g = fhe_amd.HipContext(logN, L, K, pr, ps)
