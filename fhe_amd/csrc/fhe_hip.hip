@@ -1062,7 +1062,7 @@ int fhe_hip_batch_run(fhe_hip_ctx *const *ctxs, uint32_t n_ctx, int op, uint64_t
   for (u32 g = 0; g < n_ctx; ++g) if (!ctxs[g]) return FHE_HIP_ERR_ARG;
   fhe_hip_ctx *c0 = ctxs[0];
   if (mem_kind != FHE_HIP_MEM_HOST) FAIL(c0, FHE_HIP_ERR_ARG, "fhe_hip_batch_run takes host pointers only");
-  if (op != FHE_HIP_OP_MUL_RELIN_RESCALE && op != FHE_HIP_OP_ROTATE && op != FHE_HIP_OP_ROTATE_MIXED) FAIL(c0, FHE_HIP_ERR_ARG, "unknown op");
+  if (op != FHE_HIP_OP_MUL_RELIN_RESCALE && op != FHE_HIP_OP_ROTATE && op != FHE_HIP_OP_ROTATE_MIXED && op != FHE_HIP_OP_ROTATE_NON_NTT) FAIL(c0, FHE_HIP_ERR_ARG, "unknown op");
   if (!out || (op == FHE_HIP_OP_MUL_RELIN_RESCALE && (!in0 || !in1))) FAIL(c0, FHE_HIP_ERR_ARG, "null argument");
   for (u32 g = 1; g < n_ctx; ++g)
     if (ctxs[g]->logN != c0->logN || ctxs[g]->L != c0->L || ctxs[g]->K != c0->K) FAIL(c0, FHE_HIP_ERR_ARG, "contexts of one set must share (logN, L, K)");
@@ -1083,8 +1083,10 @@ int fhe_hip_batch_run(fhe_hip_ctx *const *ctxs, uint32_t n_ctx, int op, uint64_t
         rc[g] = fhe_hip_mul_relin_rescale(ctxs[g], out + at * out_ct, in0 + at * in_ct, in1 + at * in_ct, Li, n, FHE_HIP_MEM_HOST);
       else if (op == FHE_HIP_OP_ROTATE)
         rc[g] = fhe_hip_rotate(ctxs[g], galois, out + at * out_ct, Li, n, FHE_HIP_MEM_HOST);
-      else
+      else if (op == FHE_HIP_OP_ROTATE_MIXED)
         rc[g] = fhe_hip_rotate_mixed(ctxs[g], galois, out + at * out_ct, Li, n, FHE_HIP_MEM_HOST);
+      else
+        rc[g] = fhe_hip_rotate_non_ntt(ctxs[g], galois, out + at * out_ct, Li, n, FHE_HIP_MEM_HOST);
     }
   };
   std::vector<std::thread> workers;

@@ -102,7 +102,7 @@ EXPORTED_SYMBOLS = [
     "fhe_hip_mul_relin_rescale", "fhe_hip_rotate", "fhe_hip_rotate_non_ntt", "fhe_hip_load_mixed_rot_key", "fhe_hip_rotate_mixed", "fhe_hip_decrypt", "fhe_hip_encrypt", "fhe_hip_profile_enable", "fhe_hip_profile_reset",
     "fhe_hip_profile_get", "fhe_hip_batch_run", "fhe_hip_conv_to_normal",
 ]
-OP_MUL_RELIN_RESCALE, OP_ROTATE, OP_ROTATE_MIXED = 1, 2, 3
+OP_MUL_RELIN_RESCALE, OP_ROTATE, OP_ROTATE_MIXED, OP_ROTATE_NON_NTT = 1, 2, 3, 4
 
 
 def _buf(x):

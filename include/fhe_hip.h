@@ -139,10 +139,12 @@ int fhe_hip_encrypt(fhe_hip_ctx *ctx, uint64_t *ct, const uint64_t *u, const uin
  * own threads).  Independent ciphertexts, no collective.  Returns the first non-zero status of any slice
  * (fhe_hip_last_error(ctxs[g]) has the message).
  *   FHE_HIP_OP_MUL_RELIN_RESCALE: out = [batch][2][Li-1][N], in0, in1 = [batch][2][Li][N]   (fhe_hip_mul_relin_rescale)
- *   FHE_HIP_OP_ROTATE / _ROTATE_MIXED: out = [batch][2][Li][N] in place, in0 = in1 = NULL, galois  (fhe_hip_rotate[_mixed]) */
+ *   FHE_HIP_OP_ROTATE / _ROTATE_MIXED / _ROTATE_NON_NTT: out = [batch][2][Li][N] in place, in0 = in1 = NULL, galois
+ *                                 (fhe_hip_rotate, fhe_hip_rotate_mixed, fhe_hip_rotate_non_ntt) */
 #define FHE_HIP_OP_MUL_RELIN_RESCALE 1
 #define FHE_HIP_OP_ROTATE 2
 #define FHE_HIP_OP_ROTATE_MIXED 3
+#define FHE_HIP_OP_ROTATE_NON_NTT 4
 int fhe_hip_batch_run(fhe_hip_ctx *const *ctxs, uint32_t n_ctx, int op, uint64_t *out, const uint64_t *in0, const uint64_t *in1,
                       uint64_t galois, uint32_t Li, size_t batch, int mem_kind);
 

@@ -60,6 +60,11 @@ def test_rotations_over_a_context_set():
         wb, wa = o.rotate(ct[b, 0], ct[b, 1], gal, rkb, rka)
         assert np.array_equal(work[b, 0], wb) and np.array_equal(work[b, 1], wa)
     work = ct.copy()
+    hip.batch_run(ctxs, hip.OP_ROTATE_NON_NTT, work, galois=gal, Li=Li, batch=batch)
+    for b in range(batch):
+        wb, wa = o.rotate_non_ntt(ct[b, 0], ct[b, 1], gal, rkb, rka)
+        assert np.array_equal(work[b, 0], wb) and np.array_equal(work[b, 1], wa)
+    work = ct.copy()
     hip.batch_run(ctxs, hip.OP_ROTATE_MIXED, work, galois=gal, Li=Li, batch=batch)
     for b in range(batch):
         wb, wa = o.rotate_mixed(ct[b, 0], ct[b, 1], gal, xb, xa)
