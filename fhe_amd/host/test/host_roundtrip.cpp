@@ -3,6 +3,7 @@
 // Writes every key, input and output limb to a dump file so that tests/ can re-run the same inputs through the CPU
 // checker and compare bit for bit.   usage: host_roundtrip <logN> <L> <K> <dump-file>
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
 #include <fstream>
 #include "fHE/context.hpp"
@@ -105,9 +106,14 @@ int main(int argc, char **argv) {
     std::vector<double> vals(nr_slots);
     for (size_t i = 0; i < nr_slots; ++i) vals[i] = 1.0 + (double)(i % 97) - 0.25 * (double)(i % 7);
     fHE::context::poly_t enc_poly(L);
+    const auto tc0 = std::chrono::steady_clock::now();
     encoder->encode(&enc_poly, vals, 1099511627776.0);
+    const auto tc1 = std::chrono::steady_clock::now();
     std::vector<double> back;
     encoder->decode(&back, enc_poly, 1099511627776.0);
+    const auto tc2 = std::chrono::steady_clock::now();
+    std::printf("encoder (host, 1 thread): encode %.2f ms, decode %.2f ms at N=2^%u, %u limbs\n",
+                std::chrono::duration<double, std::milli>(tc1 - tc0).count(), std::chrono::duration<double, std::milli>(tc2 - tc1).count(), logN, L);
     double enc_err = 0;
     for (size_t i = 0; i < nr_slots; ++i) enc_err = std::max(enc_err, std::fabs(back[i] - vals[i]));
     std::printf("encode/decode max error: %.3e\n", enc_err);

@@ -35,7 +35,7 @@ def _load_dump(path, N):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("logN,L,K", [(13, 4, 4), (12, 3, 2)])
+@pytest.mark.parametrize("logN,L,K", [(13, 4, 4), (12, 3, 2), (16, 4, 4)])
 def test_config1_roundtrip_through_cpp_api(tmp_path, logN, L, K):
     path = str(tmp_path / "dump.bin")
     r = subprocess.run([BIN, str(logN), str(L), str(K), path], capture_output=True, text=True, timeout=300)
