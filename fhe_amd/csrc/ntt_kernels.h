@@ -548,7 +548,9 @@ template <int LOGR> struct ColCfg {
   static constexpr int R = 1 << LOGR;
   static constexpr int LA = LOGR > 4 ? LOGR - 4 : 0;
   static constexpr int LB = LOGR > 4 ? 4 : LOGR;
-  static constexpr int CT = R >= 64 ? 16 : 16 * (64 / R);
+  // 16 columns for R = 256 (32 KiB tile, 256 threads); fewer rows take proportionally wider tiles, so that a workgroup keeps
+  // four waves and row segments grow to 256 B .. 2 KiB (N = 2^14 / 2^15: +5 % / +2.5 % over one-wave workgroups)
+  static constexpr int CT = (16 * (256 / R)) > 256 ? 256 : 16 * (256 / R);
   static constexpr int CS = CT + 1;
   static constexpr int THREADS = R * CT / 16;
 };
