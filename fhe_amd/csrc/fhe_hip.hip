@@ -67,6 +67,7 @@ struct fhe_hip_ctx {
   // workspaces (grow-only)
   void *ws[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t ws_bytes[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t relin_group = 0;  // output limbs per relinearisation pass (0 = all Li at once): fhe_hip_set_tuning
   void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[4] = {0, 0, 0, 0};
   // per-launch timing: consecutive launches share an event (end of one = start of the next) while nothing else was enqueued
@@ -196,6 +197,7 @@ struct NttPlan {
   u32 batch;
   u64 src_bstride, dst_bstride;
   u32 skip_diag = 0;
+  u32 l0 = 0;              // first limb id of this launch (limb id = grid y + l0; dst is addressed by the limb id)
   bool cols_only = false;  // run the column pass only (the row pass is fused into another kernel)
   // forward only: epilogue fused into the row pass (NttArgs::epi); dst is then only the column-pass scratch
   u32 epi = 0;
@@ -232,40 +234,19 @@ static u64 galois_inverse(u64 g, u64 N) {
   return inv & (2 * N - 1);
 }
 
-// the 8-element inverse row kernel (the only one with the fused decrypt load) serves R >= 8 unless switched off
-static bool rows8_inv_in_use(const fhe_hip_ctx *c) {
-  static const bool rows8i = [] { const char *e = getenv("FHE_HIP_ROWS8_INV"); return e ? atoi(e) != 0 : true; }();
-  return rows8i && (1u << c->logR) >= 8;
-}
-
+// row pass: 8 rows of a limb per workgroup (all R rows when R < 8), 32 threads per row
 template <bool SP, bool INV>
 int launch_rows(fhe_hip_ctx *c, const NttArgs &a, u32 nl, u32 batch) {
-  const u32 R = 1u << c->logR, rows = R < 16 ? R : 16;
+  const u32 R = 1u << c->logR, rows = R < 8 ? R : 8;
+  const dim3 grid(R / rows, nl, batch), block(32 * rows);
   if constexpr (!INV) {
-    static const bool rows8 = [] { const char *e = getenv("FHE_HIP_ROWS8"); return e ? atoi(e) != 0 : true; }();
-    if (rows8 && R >= 8) {  // 8 elements per thread, 8 rows per workgroup
-      dim3 grid8(R / 8, nl, batch), block8(256);
-      if (a.epi == 1) { LAUNCH(c, "ntt_fwd_rows_rescale", (ntt_rows8_fwd_kernel<SP, 1>), grid8, block8, a); return FHE_HIP_OK; }
-      if (a.epi == 2) { LAUNCH(c, "ntt_fwd_rows_moddown", (ntt_rows8_fwd_kernel<SP, 2>), grid8, block8, a); return FHE_HIP_OK; }
-      if (a.epi == 3) { LAUNCH(c, "ntt_fwd_rows_encrypt", (ntt_rows8_fwd_kernel<SP, 3>), grid8, block8, a); return FHE_HIP_OK; }
-      LAUNCH(c, "ntt_fwd_rows", (ntt_rows8_fwd_kernel<SP, 0>), grid8, block8, a);
-      return FHE_HIP_OK;
-    }
+    if (a.epi == 1) { LAUNCH(c, "ntt_fwd_rows_rescale", (ntt_rows8_fwd_kernel<SP, 1>), grid, block, a); return FHE_HIP_OK; }
+    if (a.epi == 2) { LAUNCH(c, "ntt_fwd_rows_moddown", (ntt_rows8_fwd_kernel<SP, 2>), grid, block, a); return FHE_HIP_OK; }
+    if (a.epi == 3) { LAUNCH(c, "ntt_fwd_rows_encrypt", (ntt_rows8_fwd_kernel<SP, 3>), grid, block, a); return FHE_HIP_OK; }
+    LAUNCH(c, "ntt_fwd_rows", (ntt_rows8_fwd_kernel<SP, 0>), grid, block, a);
+  } else {
+    LAUNCH(c, "ntt_inv_rows", (ntt_rows8_inv_kernel<SP>), grid, block, a);
   }
-  if constexpr (INV) {
-    static const bool rows8i = [] { const char *e = getenv("FHE_HIP_ROWS8_INV"); return e ? atoi(e) != 0 : true; }();
-    if (rows8i && R >= 8) {
-      LAUNCH(c, "ntt_inv_rows", (ntt_rows8_inv_kernel<SP>), dim3(R / 8, nl, batch), dim3(256), a);
-      return FHE_HIP_OK;
-    }
-  }
-  dim3 grid(R / rows, nl, batch), block(16 * rows);
-  if constexpr (!INV) {
-    if (a.epi == 1) { LAUNCH(c, "ntt_fwd_rows_rescale", (ntt_rows_kernel<SP, false, 1>), grid, block, a); return FHE_HIP_OK; }
-    if (a.epi == 2) { LAUNCH(c, "ntt_fwd_rows_moddown", (ntt_rows_kernel<SP, false, 2>), grid, block, a); return FHE_HIP_OK; }
-    if (a.epi == 3) { LAUNCH(c, "ntt_fwd_rows_encrypt", (ntt_rows_kernel<SP, false, 3>), grid, block, a); return FHE_HIP_OK; }
-  }
-  LAUNCH(c, INV ? "ntt_inv_rows" : "ntt_fwd_rows", (ntt_rows_kernel<SP, INV>), grid, block, a);
   return FHE_HIP_OK;
 }
 
@@ -275,7 +256,7 @@ int ntt_run_sp(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
   NttArgs a;
   a.tw = inverse ? c->d_tw_inv : c->d_tw_fwd;
   a.primes = c->d_primes; a.midx = p.midx; a.mdiv = p.mdiv; a.mper = p.mper;
-  a.logN = c->logN; a.logR = c->logR; a.l0 = 0; a.skip_diag = p.skip_diag;
+  a.logN = c->logN; a.logR = c->logR; a.l0 = p.l0; a.skip_diag = p.skip_diag;
   a.dst = p.dst; a.dst_bstride = p.dst_bstride;
   a.epi = inverse ? 0 : p.epi; a.epi_src = p.epi_src; a.epi_c = p.epi_c; a.epi_add = p.epi_add; a.epi_out = p.epi_out;
   a.epi_src_bstride = p.epi_src_bstride; a.epi_add_bstride = p.epi_add_bstride; a.epi_out_bstride = p.epi_out_bstride;
@@ -299,12 +280,6 @@ int ntt_run(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
   // grid.y / grid.z limits: split large limb counts over several launches
   if (p.nl > 65535 || p.batch > 65535) FAIL(c, FHE_HIP_ERR_RANGE, "too many limbs in one NTT launch");
   return c->sp ? ntt_run_sp<true>(c, p, inverse) : ntt_run_sp<false>(c, p, inverse);
-}
-
-// in-place NTT of nl limbs per entry using the identity modulus map (limb k -> modulus first+k)
-int ntt_simple(fhe_hip_ctx *c, u64 *data, const u32 *midx, u32 nl, u32 batch, u64 bstride, bool inverse) {
-  NttPlan p{data, data, midx, 1, nl, nl, nl, batch, bstride, bstride};
-  return ntt_run(c, p, inverse);
 }
 
 dim3 pw_grid(const fhe_hip_ctx *c, u32 y, u32 z) { return dim3((unsigned)(c->N / (2 * PW_THREADS)), y, z); }
@@ -354,6 +329,7 @@ int check_ctx(fhe_hip_ctx *c) {
 
 // BaseConverter::approximated_mod_up body on device: special limbs of rop from power-basis op
 int dev_conv_to_special(fhe_hip_ctx *c, u64 *rop, u32 rop_limbs, u32 rop_off, const u64 *op, u32 op_limbs, u32 Li, u32 batch, bool pre_scaled = false) {
+  if (c->K == 0 || batch == 0) return FHE_HIP_OK;  // nothing to convert to
   BconvArgs a;
   a.out = rop; a.src = op;
   a.inv_m = c->d_hat_qj_inv_m + (size_t)(Li - 2) * c->L;
@@ -412,33 +388,42 @@ int dev_rescale(fhe_hip_ctx *c, u64 *rop, const u64 *op, u32 n, u32 entries, int
   return FHE_HIP_OK;
 }
 
-// Mul::reLinearize: ct3 [b][3][Li][N] -> out [b][2][Li][N]
-// launch of the fused digit-NTT + key-MAC kernel: 8 elements per thread (more waves in flight) unless FHE_HIP_RELIN8=0 or R < 8
-int launch_relin(fhe_hip_ctx *c, RelinArgs &ra, u32 nb, u32 nout) {
-  const u32 R = 1u << c->logR;
-  static const bool relin8 = [] { const char *e = getenv("FHE_HIP_RELIN8"); return e ? atoi(e) != 0 : true; }();
-  ra.nb = nb;
-  if (relin8 && R >= 8) {
-    ra.rb_count = R / 8;
-    LAUNCH_SP(c, "relin_rows_mac", relin_rows8p_mac_kernel, dim3(nb * (R / 8) * nout), dim3(256), ra);
-  } else {
-    const u32 rows = R < 16 ? R : 16;
-    ra.rb_count = R / rows;
-    LAUNCH_SP(c, "relin_rows_mac", relin_rows_mac_kernel, dim3(nb * (R / rows) * nout), dim3(16 * rows), ra);
+// Digit key switch shared by Mul::reLinearize (src/evaluator.cpp:663-691) and apply_rotation_key(MixedRotKey) (:424-473):
+// column pass of the nout*nd digit NTTs (diagonal skipped), then the fused row pass + key MAC.  The column-pass output t1 is
+// produced and consumed in groups of `group` output limbs ([b][group][nd][N] at a time), which bounds its size.
+// ra carries everything but t1 / i0 / gi / nb / rb_count; pw = [b][nd][N] power-basis digits.
+int run_digit_keyswitch(fhe_hip_ctx *c, RelinArgs ra, const u64 *pw, u64 *t1, const u32 *omap, u32 nout, u32 nd, u32 nb, u32 group) {
+  const u64 N = c->N;
+  const u32 R = 1u << c->logR, rows = R < 8 ? R : 8;
+  ra.nb = nb; ra.rb_count = R / rows; ra.omap = omap; ra.nd = nd; ra.nout = nout; ra.logN = c->logN; ra.logR = c->logR;
+  ra.tw = c->d_tw_fwd; ra.primes = c->d_primes; ra.t1 = t1;
+  for (u32 i0 = 0; i0 < nout; i0 += group) {
+    const u32 gi = nout - i0 < group ? nout - i0 : group;
+    // limb id = i*nd + j uses modulus omap[i] and source digit j; ids i0*nd .. (i0+gi)*nd - 1, written group-relative
+    NttPlan pf{pw, t1 - (size_t)i0 * nd * N, omap, nd, nout, nd, gi * nd, nb, (u64)nd * N, (u64)gi * nd * N};
+    pf.l0 = i0 * nd; pf.skip_diag = nd; pf.cols_only = true;
+    TRY(ntt_run(c, pf, false));
+    ra.i0 = i0; ra.gi = gi;
+    LAUNCH_SP(c, "relin_rows_mac", relin_rows8p_mac_kernel, dim3(nb * ra.rb_count * gi), dim3(32 * rows), ra);
   }
   return FHE_HIP_OK;
 }
 
+// Mul::reLinearize: ct3 [b][3][Li][N] -> out [b][2][Li][N]
 int dev_relin(fhe_hip_ctx *c, u64 *out, const u64 *ct3, u32 Li, u32 batch) {
   const u64 N = c->N;
   if (!c->d_mk_beta) FAIL(c, FHE_HIP_ERR_NOKEY, "mult key not loaded");
-  // bound the Li^2 intermediate: process the batch in chunks of at most 8 GiB
-  const size_t per_ct = (size_t)Li * Li * N * 8;
-  u32 chunk = (u32)((8ull << 30) / per_ct);
-  if (chunk < 1) chunk = 1;
-  if (chunk > batch) chunk = batch;
+  u32 group = c->relin_group ? (c->relin_group < Li ? c->relin_group : Li) : Li;
+  u32 chunk = batch;
+  {
+    // bound the intermediate: process the batch in chunks of at most 8 GiB
+    const size_t per_ct = (size_t)group * Li * N * 8;
+    chunk = (u32)((8ull << 30) / per_ct);
+    if (chunk < 1) chunk = 1;
+    if (chunk > batch) chunk = batch;
+  }
   TRY(ensure_ws(c, 0, (size_t)chunk * Li * N * 8));
-  TRY(ensure_ws(c, 1, (size_t)chunk * per_ct));
+  TRY(ensure_ws(c, 1, (size_t)chunk * group * Li * N * 8));
   u64 *pw = (u64 *)c->ws[0], *t = (u64 *)c->ws[1];
   for (u32 b0 = 0; b0 < batch; b0 += chunk) {
     const u32 nb = (batch - b0 < chunk) ? batch - b0 : chunk;
@@ -446,19 +431,14 @@ int dev_relin(fhe_hip_ctx *c, u64 *out, const u64 *ct3, u32 Li, u32 batch) {
     // ct2_power = INTT(ct[2])   (evaluator.cpp:659-660)
     NttPlan pi{in + (size_t)2 * Li * N, pw, c->d_iota, 1, Li, Li, Li, nb, (u64)3 * Li * N, (u64)Li * N};
     TRY(ntt_run(c, pi, true));
-    // column pass of t[i][j] = NTT_i(ct2_power[j]) (evaluator.cpp:666-668), limb id = i*Li + j, j == i skipped;
-    // the row pass, the key MAC (:672-679) and the final "+ ct[l]" (:682-691) are fused in relin_rows_mac_kernel
-    NttPlan pf{pw, t, c->d_iota, Li, Li, Li, Li * Li, nb, (u64)Li * N, (u64)Li * Li * N};
-    pf.skip_diag = Li; pf.cols_only = true;
-    TRY(ntt_run(c, pf, false));
+    // t[i][j] = NTT_i(ct2_power[j]) (evaluator.cpp:666-668), j == i skipped; the row pass, the key MAC (:672-679) and the
+    // final "+ ct[l]" (:682-691) are fused in relin_rows8p_mac_kernel
     RelinArgs ra;
-    ra.t1 = t; ra.out = out + (size_t)b0 * 2 * Li * N;
+    ra.out = out + (size_t)b0 * 2 * Li * N;
     ra.diag = in + (size_t)2 * Li * N; ra.diag_bstride = (u64)3 * Li * N;            // ct[2] limb i (j == i)
     ra.add0 = in; ra.add1 = in + (size_t)Li * N; ra.add_bstride = (u64)3 * Li * N;   // + ct[0], + ct[1]
     ra.beta_m = c->d_mk_beta; ra.alpha_m = c->d_mk_alpha; ra.klimbs = c->L;
-    ra.tw = c->d_tw_fwd; ra.primes = c->d_primes; ra.omap = c->d_iota;
-    ra.nd = Li; ra.nout = Li; ra.logN = c->logN; ra.logR = c->logR;
-    TRY(launch_relin(c, ra, nb, Li));
+    TRY(run_digit_keyswitch(c, ra, pw, t, c->d_iota, Li, Li, nb, group));
   }
   return FHE_HIP_OK;
 }
@@ -476,6 +456,7 @@ int dev_mul_relin_rescale(fhe_hip_ctx *c, u64 *out, const u64 *c0, const u64 *c1
   const u64 N = c->N;
   TRY(ensure_ws(c, 3, (size_t)batch * 3 * Li * N * 8));
   TRY(ensure_ws(c, 4, (size_t)batch * 2 * Li * N * 8));
+  TRY(ensure_ws(c, 2, (size_t)batch * 2 * (Li - 1) * N * 8));  // rescale tails (dev_rescale), reserved before dev_relin sizes its own
   u64 *ct3 = (u64 *)c->ws[3], *rl = (u64 *)c->ws[4];
   LAUNCH_SP(c, "cross_mult", cross_mult_kernel, pw_grid(c, Li, batch), dim3(PW_THREADS), ct3, c0, c1, (const PrimeC *)c->d_primes, Li, N);
   TRY(dev_relin(c, rl, ct3, Li, batch));
@@ -523,8 +504,7 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
            (const u32 *)perm, N, (u64)2 * Li * N, g_bstride);
   }
   const u64 *axg = fused ? ct + (size_t)Li * N : g + (size_t)Li * N;  // galois(ax), through perm when fused
-  static const bool sp_fusion = [] { const char *e = getenv("FHE_HIP_ROT_FUSED"); return e ? atoi(e) != 0 : true; }();
-  const bool fused_sp = sp_fusion && !non_ntt && c->logR >= 3;
+  const bool fused_sp = !non_ntt;  // NTT path: special limbs go through rot_special_rows8_kernel
   if (non_ntt) {
     // ax_g is already in the power basis (:537): mod up, then forward NTT of all Li+K limbs (:539-542)
     TRY(dev_conv_to_special(c, e0, nl, Li, g + (size_t)Li * N, 2 * Li, Li, batch));
@@ -541,10 +521,10 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
     // mod up: special limbs from the power basis; normal limbs of the NTT-domain result are ax_g itself
     // (NTT(INTT(x)) = x for canonical x, so the Li forward NTTs of :363-366 are not recomputed)
     TRY(dev_conv_to_special(c, e0, nl, Li, pw, Li, Li, batch, true));
-    // forward NTT of the K special limbs: column pass here; for R >= 8 the row pass, both key products and the row pass of
-    // the two inverse NTTs (:363-392 for cm >= Li) run fused in rot_special_rows8_kernel
+    // forward NTT of the K special limbs: column pass here; the row pass, both key products and the row pass of the two
+    // inverse NTTs (:363-392 for cm >= Li) run fused in rot_special_rows8_kernel
     NttPlan pf{e0 + (size_t)Li * N, e0 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
-    pf.cols_only = fused_sp;
+    pf.cols_only = true;
     TRY(ntt_run(c, pf, false));
   }
   const u32 *rotmap = c->d_rotmap + (size_t)Li * c->M;
@@ -553,7 +533,8 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
     ra.e0 = e0; ra.e1 = e1; ra.beta_m = it->second.beta_m; ra.alpha_m = it->second.alpha_m;
     ra.tw_fwd = c->d_tw_fwd; ra.tw_inv = c->d_tw_inv; ra.primes = c->d_primes;
     ra.first_mod = c->L; ra.first_limb = Li; ra.nl = nl; ra.logN = c->logN; ra.logR = c->logR;
-    LAUNCH_SP(c, "rot_special_rows", rot_special_rows8_kernel, dim3((1u << c->logR) / 8, K, batch), dim3(256), ra);
+    const u32 R = 1u << c->logR, rows = R < 8 ? R : 8;
+    LAUNCH_SP(c, "rot_special_rows", rot_special_rows8_kernel, dim3(R / rows, K, batch), dim3(32 * rows), ra);
     // key product of the Li normal limbs (read through the galois table when fused)
     LAUNCH_SP(c, "rot_keymul", rot_keymul_kernel, pw_grid(c, Li, batch), dim3(PW_THREADS), e0, e1, (const u64 *)e0, (const u64 *)it->second.beta_m,
               (const u64 *)it->second.alpha_m, (const PrimeC *)c->d_primes, rotmap, nl, N, axg, (u64)2 * Li * N, Li, (const u32 *)(fused ? perm : nullptr));
@@ -563,23 +544,13 @@ int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_
       pc.cols_only = true; pc.inv_scale = c->d_moddown_scale_m;  // special limbs come out as mod-down digits
       TRY(ntt_run(c, pc, true));
     }
-  } else {
+  } else {  // power-basis variant: key product over all Li+K limbs, then every limb back to the power basis (:544-567)
     LAUNCH_SP(c, "rot_keymul", rot_keymul_kernel, pw_grid(c, nl, batch), dim3(PW_THREADS), e0, e1, (const u64 *)e0, (const u64 *)it->second.beta_m,
-              (const u64 *)it->second.alpha_m, (const PrimeC *)c->d_primes, rotmap, nl, N,
-              (const u64 *)(non_ntt ? nullptr : axg), (u64)2 * Li * N, Li, (const u32 *)(fused ? perm : nullptr));  // NTT path: normal limbs straight from ax_g
-    if (non_ntt) {  // every limb back to the power basis (:563-567)
-      NttPlan p0{e0, e0, c->d_rotmap + (size_t)Li * c->M, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
-      TRY(ntt_run(c, p0, true));
-      NttPlan p1{e1, e1, c->d_rotmap + (size_t)Li * c->M, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
-      TRY(ntt_run(c, p1, true));
-    } else {  // special limbs back to the power basis (:386-392)
-      NttPlan p0{e0 + (size_t)Li * N, e0 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
-      p0.inv_scale = c->d_moddown_scale_m;
-      TRY(ntt_run(c, p0, true));
-      NttPlan p1{e1 + (size_t)Li * N, e1 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
-      p1.inv_scale = c->d_moddown_scale_m;
-      TRY(ntt_run(c, p1, true));
-    }
+              (const u64 *)it->second.alpha_m, (const PrimeC *)c->d_primes, rotmap, nl, N, (const u64 *)nullptr, (u64)2 * Li * N, Li, (const u32 *)nullptr);
+    NttPlan p0{e0, e0, c->d_rotmap + (size_t)Li * c->M, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
+    TRY(ntt_run(c, p0, true));
+    NttPlan p1{e1, e1, c->d_rotmap + (size_t)Li * c->M, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
+    TRY(ntt_run(c, p1, true));
   }
   // mod down both halves straight into ct (strided [b][2][Li][N]); rop[0] += galois(bx) read from g (:394-398)
   TRY(ensure_ws(c, 2, (size_t)batch * Li * N * 8));
@@ -618,19 +589,14 @@ int dev_rotate_mixed(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch) {
   // [ct_1]_qi -> power basis (:425-427)
   NttPlan pi{g + (size_t)Li * N, pw, c->d_iota, 1, Li, Li, Li, batch, (u64)2 * Li * N, (u64)Li * N};
   TRY(ntt_run(c, pi, true));
-  // column pass of NTT_{j}(digit i) for the Li+1 targets (limb id = j*Li + i), diagonal skipped (:436-437)
+  // NTT_j(digit i) for the Li+1 targets (limb id = j*Li + i), diagonal skipped (:436-437), fused with the key MAC
   const u32 *omap = c->d_rotmap + (size_t)Li * c->M;   // j < Li ? j : L
-  NttPlan pf{pw, t, omap, Li, nout, Li, nout * Li, batch, (u64)Li * N, (u64)nout * Li * N};
-  pf.skip_diag = Li; pf.cols_only = true;
-  TRY(ntt_run(c, pf, false));
   RelinArgs ra;
-  ra.t1 = t; ra.out = ans;
+  ra.out = ans;
   ra.diag = g + (size_t)Li * N; ra.diag_bstride = (u64)2 * Li * N;
   ra.add0 = nullptr; ra.add1 = nullptr; ra.add_bstride = 0;
   ra.beta_m = it->second.beta_m; ra.alpha_m = it->second.alpha_m; ra.klimbs = c->L + 1;
-  ra.tw = c->d_tw_fwd; ra.primes = c->d_primes; ra.omap = omap;
-  ra.nd = Li; ra.nout = nout; ra.logN = c->logN; ra.logR = c->logR;
-  TRY(launch_relin(c, ra, batch, nout));
+  TRY(run_digit_keyswitch(c, ra, pw, t, omap, nout, Li, batch, nout));
   // rescale by the special prime (:475-515): entries = 2*batch polys of Li+1 limbs, last limb lives under P[L]
   NttPlan pl{ans + (size_t)Li * N, ans + (size_t)Li * N, c->d_iota + c->L, 1, 1, 1, 1, 2 * batch, (u64)nout * N, (u64)nout * N};
   TRY(ntt_run(c, pl, true));
@@ -681,6 +647,19 @@ int fhe_hip_ctx_create(fhe_hip_ctx **out, uint32_t logN, uint32_t L, uint32_t K,
     if (p >= (1ull << 62) || p < (1ull << 20) || (p - 1) % (2 * N) != 0) { c->err = "prime out of contract (p < 2^62, 2N | p-1)"; return fail(FHE_HIP_ERR_RANGE); }
     if (h_powmod(psi[m], N, p) != p - 1) { c->err = "psi is not a primitive 2N-th root of unity"; return fail(FHE_HIP_ERR_RANGE); }
     if ((p & 0xFFFFFFFFull) != 1) c->sp = false;
+  }
+  {
+    // the lazy butterflies take residues of one prime of the table as inputs under another (relinearisation digits, rescale
+    // tails, mixed rotation) and need them below 4p: primes of one table must lie within a factor 4 of each other; equal
+    // primes have no inverse modulo each other
+    u64 pmin = primes[0], pmax = primes[0];
+    for (uint32_t m = 0; m < M; ++m) {
+      if (primes[m] < pmin) pmin = primes[m];
+      if (primes[m] > pmax) pmax = primes[m];
+      for (uint32_t k = 0; k < m; ++k)
+        if (primes[k] == primes[m]) { c->err = "duplicate prime in the table"; return fail(FHE_HIP_ERR_RANGE); }
+    }
+    if (pmax / 4 >= pmin) { c->err = "primes of one table must satisfy max(p) < 4 * min(p) (lazy reduction across primes)"; return fail(FHE_HIP_ERR_RANGE); }
   }
   std::vector<PrimeC> pc(M);
   std::vector<u64> twf((size_t)M * N), twi((size_t)M * N);
@@ -832,6 +811,11 @@ int fhe_hip_mod_up(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t L
   if (Li <= 1) FAIL(c, FHE_HIP_ERR_RANGE, "nmoduli <= 1");  // base_converter.cpp:284-285
   if (batch == 0) return FHE_HIP_OK;
   const u64 N = c->N; const u32 nl = Li + c->K;
+  if (c->K == 0) {  // no special primes: the result is the copy of the normal limbs (:196-197), no conversion to launch
+    if (mem_kind == FHE_HIP_MEM_DEVICE) HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(rop, op, batch * Li * N * 8, hipMemcpyDeviceToDevice, c->stream)));
+    else std::memmove(rop, op, batch * Li * N * 8);
+    return FHE_HIP_OK;
+  }
   Staged st(c, mem_kind);
   const u64 *dop = nullptr; u64 *drop = nullptr;
   TRY(st.in(op, batch * Li * N * 8, &dop));
@@ -1030,6 +1014,12 @@ int fhe_hip_mul_relin_rescale(fhe_hip_ctx *c, uint64_t *out, const uint64_t *c0,
   } catch (...) { return abi_exception(); }
 }
 
+int fhe_hip_set_tuning(fhe_hip_ctx *c, int knob, uint64_t value) {
+  TRY(check_ctx(c));
+  if (knob == FHE_HIP_TUNE_RELIN_GROUP) { c->relin_group = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return FHE_HIP_OK; }
+  FAIL(c, FHE_HIP_ERR_ARG, "unknown tuning knob");
+}
+
 static int rotate_api(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind, bool non_ntt) {
   try {
   TRY(check_ctx(c));
@@ -1148,15 +1138,10 @@ int fhe_hip_decrypt(fhe_hip_ctx *c, uint64_t *out, const uint64_t *ct, const uin
   TRY(st.in(ct, batch * 2 * Li * N * 8, &dct));
   TRY(st.in(sx, (size_t)Li * N * 8, &dsx));
   TRY(st.out(out, batch * Li * N * 8, &dout, false));
-  if (rows8_inv_in_use(c)) {
-    // bx + sx * ax (decryptor.cpp:24-35) is formed while the inverse row pass loads its rows; rop->backward() (:36) follows
-    NttPlan p{dct, dout, c->d_iota, 1, Li, Li, Li, (u32)batch, (u64)2 * Li * N, (u64)Li * N};
-    p.pre_a = dct + (size_t)Li * N; p.pre_k = dsx;
-    TRY(ntt_run(c, p, true));
-  } else {
-    LAUNCH_SP(c, "decrypt_mac", decrypt_mac_kernel, pw_grid(c, Li, (u32)batch), dim3(PW_THREADS), dout, dct, dsx, (const PrimeC *)c->d_primes, Li, N);
-    TRY(ntt_simple(c, dout, c->d_iota, Li, (u32)batch, (u64)Li * N, true));  // rop->backward(), decryptor.cpp:36
-  }
+  // bx + sx * ax (decryptor.cpp:24-35) is formed while the inverse row pass loads its rows; rop->backward() (:36) follows
+  NttPlan p{dct, dout, c->d_iota, 1, Li, Li, Li, (u32)batch, (u64)2 * Li * N, (u64)Li * N};
+  p.pre_a = dct + (size_t)Li * N; p.pre_k = dsx;
+  TRY(ntt_run(c, p, true));
   return st.finish();
   } catch (...) { return abi_exception(); }
 }

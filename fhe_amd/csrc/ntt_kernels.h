@@ -8,9 +8,9 @@
 //
 // Decomposition: N = R x 256.  Forward = column pass (stages 0..logR-1, stride-256 butterflies over an
 // R x CT tile held in LDS) then row pass (stages logR..logN-1 inside contiguous 256-element rows).
-// Inverse = row pass then column pass (+ N^-1).  Inside a pass every thread keeps 16 elements in
-// registers for 4 stages (radix-16), exchanging through LDS once; values stay lazy ([0,4p) forward,
-// [0,2p) inverse) and are made canonical only by the last pass.
+// Inverse = row pass then column pass (+ N^-1).  Column pass: every thread keeps 16 elements in registers for
+// 4 stages (radix-16), exchanging through LDS once; row pass: 8 elements per thread, register phases of 3 + 3 + 2
+// stages.  Values stay lazy ([0,4p) forward, [0,2p) inverse) and are made canonical only by the last pass.
 #pragma once
 #include "modarith.h"
 
@@ -42,7 +42,7 @@ struct NttArgs {
   u64 epi_src_bstride, epi_add_bstride, epi_out_bstride;
 };
 
-// LDS hand-off inside one wave (a 256-element row is owned by 16 consecutive lanes of one wave)
+// LDS hand-off inside one wave (a 256-element row is owned by 32 consecutive lanes of one wave)
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -66,19 +66,11 @@ __device__ __forceinline__ void fwd_phase(u64 (&e)[1 << LK], const u64 *__restri
     const int half = 1 << (LK - 1 - q);
 #pragma unroll
     for (int kk = 0; kk < (1 << q); ++kk) {
-#if defined(NTT_ABL) && NTT_ABL == 3
-      const u64 W = P.r2 + base + kk;
-#else
       const u64 W = tw[(base << q) + kk];
-#endif
 #pragma unroll
       for (int j = 0; j < half; ++j) {
         const int a = kk * 2 * half + j;
-#if defined(NTT_ABL) && NTT_ABL == 1
-        e[a] += W; e[a + half] ^= W;
-#else
         ct_bfly<SP>(e[a], e[a + half], W, P);
-#endif
       }
     }
   }
@@ -139,139 +131,10 @@ __device__ __forceinline__ void inv_phase(u64 (&e)[1 << LK], const u64 *__restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row pass: 8 stages inside contiguous 256-element rows.  Block = 16*ROWS threads, ROWS rows of one limb.
-// LDS image per row: 16 chunks of 16 elements, chunk stride 18 (conflict-free ds_read_b128).
-// ---------------------------------------------------------------------------------------------
-constexpr int ROW_LDS = 16 * 18;
-
-template <bool SP, bool INVERSE, int EPI = 0>
-__global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
-#if defined(NTT_ABL) && NTT_ABL == 4
-  __shared__ __attribute__((aligned(16))) u64 lds[32 * ROW_LDS];  // occupancy experiment: 2 workgroups per CU
-#else
-  __shared__ __attribute__((aligned(16))) u64 lds[16 * ROW_LDS];
-#endif
-  const u32 tid = threadIdx.x, rloc = tid >> 4, t = tid & 15;
-  const u32 rows_per_wg = blockDim.x >> 4;
-  const u32 row = blockIdx.x * rows_per_wg + rloc;
-  const u32 l = blockIdx.y + a.l0, b = blockIdx.z;
-  const u32 m = a.midx[(l / a.mdiv) % a.mper];
-  const PrimeC P = a.primes[m];
-  const u64 N = 1ull << a.logN;
-  const u64 *__restrict__ tw = a.tw + (u64)m * N;
-  const u64 *s = a.src + (u64)b * a.src_bstride + (u64)(l % a.smod) * N + (u64)row * 256;
-  u64 *d = a.dst + (u64)b * a.dst_bstride + (u64)l * N + (u64)row * 256;
-  u64 *L = lds + rloc * ROW_LDS;
-  const u32 baseA = (1u << a.logR) + row;
-  u64 e[16];
-  if constexpr (!INVERSE) {
-    // phase A: spans 128..16, thread holds {t + 16k}
-#pragma unroll
-#if defined(NTT_ABL) && NTT_ABL == 2
-    for (int k = 0; k < 16; ++k) e[k] = (u64)tid * 0x9E3779B97F4A7C15ull + k + P.r2;
-#else
-    for (int k = 0; k < 16; ++k) e[k] = s[t + 16 * k];
-#endif
-    fwd_phase<SP, 4>(e, tw, baseA, P);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) L[k * 18 + t] = e[k];
-    wave_lds_sync();
-    // phase B: spans 8..1, thread holds {16t + k}
-#pragma unroll
-    for (int k = 0; k < 16; k += 2) {
-      const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[t * 18 + k]);
-      e[k] = v.x; e[k + 1] = v.y;
-    }
-    fwd_phase<SP, 4>(e, tw, (baseA << 4) + t, P);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) e[k] = (EPI == 0) ? canon4(e[k], P) : csub(e[k], P.twop);  // epilogue takes t in [0,2p)
-    wave_lds_sync();
-#pragma unroll
-    for (int k = 0; k < 16; k += 2) *reinterpret_cast<ulonglong2 *>(&L[t * 18 + k]) = make_ulonglong2(e[k], e[k + 1]);
-    wave_lds_sync();
-    // coalesced 16-byte stores: instruction i covers elements [32i, 32i+32) of the row
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[(2 * i + (t >> 3)) * 18 + ((2 * t) & 15)]);
-#if defined(NTT_ABL) && NTT_ABL == 2
-      if (v.x == 0x123456789ull) d[32 * i + 2 * t] = v.y;
-#else
-      if constexpr (EPI == 0) {
-        *reinterpret_cast<ulonglong2 *>(&d[32 * i + 2 * t]) = v;
-      } else {
-        const u64 off = (u64)l * N + (u64)row * 256 + 32 * i + 2 * t;
-        const ulonglong2 h = *reinterpret_cast<const ulonglong2 *>(&a.epi_src[(u64)b * a.epi_src_bstride + off]);
-        u64 r0, r1;
-        [[maybe_unused]] u64 cm = 0;
-        if constexpr (EPI != 3) cm = a.epi_c[m];
-        if constexpr (EPI == 3) {
-          // Encryptor::encrypt add_product_of (src/encryptor.cpp:31,35): out = NTT(e) + u^ * pk, u^ = epi_src, pk = epi_add
-          const ulonglong2 pk = *reinterpret_cast<const ulonglong2 *>(&a.epi_add[(u64)b * a.epi_add_bstride + off]);
-          r0 = csub(mulmod_full<SP>(pk.x, h.x, P) + csub(v.x, P.p), P.p);
-          r1 = csub(mulmod_full<SP>(pk.y, h.y, P) + csub(v.y, P.p), P.p);
-        } else if constexpr (EPI == 1) {
-          r0 = csub(mont_mul<SP>(cm, h.x + P.twop - v.x, P), P.p);
-          r1 = csub(mont_mul<SP>(cm, h.y + P.twop - v.y, P), P.p);
-          if (a.epi_add) {  // MixedRotKey tail: rop[0] = ct[0] + ... (src/evaluator.cpp:503-514)
-            const ulonglong2 ad = *reinterpret_cast<const ulonglong2 *>(&a.epi_add[(u64)b * a.epi_add_bstride + off]);
-            r0 = csub(r0 + ad.x, P.p); r1 = csub(r1 + ad.y, P.p);
-          }
-        } else {
-          r0 = csub(mont_mul<SP>(cm, h.x + v.x, P), P.p);
-          r1 = csub(mont_mul<SP>(cm, h.y + v.y, P), P.p);
-          if (a.epi_add) {
-            ulonglong2 ad;
-            if (a.epi_add_perm) {
-              const u64 *al = a.epi_add + (u64)b * a.epi_add_bstride + (u64)l * N;
-              const uint2 pi = *reinterpret_cast<const uint2 *>(&a.epi_add_perm[row * 256 + 32 * i + 2 * t]);
-              ad = make_ulonglong2(al[pi.x], al[pi.y]);
-            } else {
-              ad = *reinterpret_cast<const ulonglong2 *>(&a.epi_add[(u64)b * a.epi_add_bstride + off]);
-            }
-            r0 = csub(r0 + ad.x, P.p); r1 = csub(r1 + ad.y, P.p);
-          }
-        }
-        *reinterpret_cast<ulonglong2 *>(&a.epi_out[(u64)b * a.epi_out_bstride + off]) = make_ulonglong2(r0, r1);
-      }
-#endif
-    }
-  } else {
-    // inverse: spans 1..8 first (thread holds {16t + k}), then spans 16..128 ({t + 16k}); output lazy [0,2p)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      ulonglong2 v;
-      if (a.perm) {
-        const u64 *sl = s - (u64)row * 256;  // limb base
-        const uint2 pi = *reinterpret_cast<const uint2 *>(&a.perm[row * 256 + 32 * i + 2 * t]);
-        v = make_ulonglong2(sl[pi.x], sl[pi.y]);
-      } else {
-        v = *reinterpret_cast<const ulonglong2 *>(&s[32 * i + 2 * t]);
-      }
-      *reinterpret_cast<ulonglong2 *>(&L[(2 * i + (t >> 3)) * 18 + ((2 * t) & 15)]) = v;
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int k = 0; k < 16; k += 2) {
-      const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[t * 18 + k]);
-      e[k] = v.x; e[k + 1] = v.y;
-    }
-    inv_phase<SP, 4>(e, tw, (baseA << 4) + t, P);
-    wave_lds_sync();
-#pragma unroll
-    for (int k = 0; k < 16; k += 2) *reinterpret_cast<ulonglong2 *>(&L[t * 18 + k]) = make_ulonglong2(e[k], e[k + 1]);
-    wave_lds_sync();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) e[k] = L[k * 18 + t];
-    inv_phase<SP, 4>(e, tw, baseA, P);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) d[t + 16 * k] = e[k];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Row pass, 8 elements per thread (forward): 32 threads per 256-element row, three register phases of 3 + 3 + 2 stages.
-// Half the registers and half the LDS per thread of the 16-element version, so twice the waves per SIMD to hide the
-// global-memory latency.  LDS image per row: 8 chunks of 32 elements at chunk stride 36 (conflict-free strided reads).
+// Row pass (forward): 8 stages inside contiguous 256-element rows; 32 threads per row with 8 elements each, three
+// register phases of 3 + 3 + 2 stages, up to 8 rows per workgroup.  A row is owned by 32 consecutive lanes of one wave,
+// so the exchanges need only wave-level ordering (no s_barrier).  LDS image per row: 8 chunks of 32 elements at chunk
+// stride 36 (conflict-free strided reads).
 // ---------------------------------------------------------------------------------------------
 constexpr int ROW8_LDS = 8 * 36;
 __device__ __forceinline__ u32 row8_pos(u32 e) { return (e >> 5) * 36 + (e & 31); }
@@ -280,7 +143,7 @@ template <bool SP, int EPI = 0>
 __global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
   __shared__ __attribute__((aligned(16))) u64 lds[8 * ROW8_LDS];
   const u32 tid = threadIdx.x, rloc = tid >> 5, t = tid & 31;
-  const u32 row = blockIdx.x * 8 + rloc;
+  const u32 row = blockIdx.x * (blockDim.x >> 5) + rloc;  // 8 rows per workgroup (R < 8: all R rows, 32 * R threads)
   const u32 l = blockIdx.y + a.l0, b = blockIdx.z;
   const u32 m = a.midx[(l / a.mdiv) % a.mper];
   const PrimeC P = a.primes[m];
@@ -382,7 +245,7 @@ template <bool SP>
 __global__ __launch_bounds__(256) void ntt_rows8_inv_kernel(NttArgs a) {
   __shared__ __attribute__((aligned(16))) u64 lds[8 * ROW8_LDS];
   const u32 tid = threadIdx.x, rloc = tid >> 5, t = tid & 31;
-  const u32 row = blockIdx.x * 8 + rloc;
+  const u32 row = blockIdx.x * (blockDim.x >> 5) + rloc;  // 8 rows per workgroup (R < 8: all R rows, 32 * R threads)
   const u32 l = blockIdx.y + a.l0, b = blockIdx.z;
   const u32 m = a.midx[(l / a.mdiv) % a.mper];
   const PrimeC P = a.primes[m];
@@ -465,7 +328,7 @@ template <bool SP>
 __global__ __launch_bounds__(256) void rot_special_rows8_kernel(RotSpArgs a) {
   __shared__ __attribute__((aligned(16))) u64 lds[8 * ROW8_LDS];
   const u32 tid = threadIdx.x, rloc = tid >> 5, t = tid & 31;
-  const u32 row = blockIdx.x * 8 + rloc;
+  const u32 row = blockIdx.x * (blockDim.x >> 5) + rloc;  // 8 rows per workgroup (R < 8: all R rows, 32 * R threads)
   const u32 m = a.first_mod + blockIdx.y, b = blockIdx.z;
   const PrimeC P = a.primes[m];
   const u64 N = 1ull << a.logN;
@@ -651,7 +514,7 @@ __global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs
 // normal primes plus the special prime P[L] (omap), the digits are the limbs of galois(ax), the diagonal digit is ct[1]
 // itself (:436-437) and nothing is added.
 struct RelinArgs {
-  const u64 *t1;           // [b][nout][nd][N] column-pass output
+  const u64 *t1;           // [b][gi][nd][N] column-pass output of the output limbs i0 .. i0+gi-1
   const u64 *diag;         // digit j == output limb i: [b](diag_bstride)[limb][N], read directly
   const u64 *add0, *add1;  // optional addends per half: [b](add_bstride)[limb][N]; null = none
   u64 *out;                // [b][2][nout][N]
@@ -661,107 +524,11 @@ struct RelinArgs {
   u64 diag_bstride, add_bstride;
   u32 nd, nout, klimbs, logN, logR;
   u32 nb, rb_count;        // batch entries and row blocks per limb (grid decode)
+  u32 i0, gi;              // this launch covers output limbs i0 .. i0+gi-1 (a group: bounds the size of t1)
 };
 
-template <bool SP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void relin_rows_mac_kernel(RelinArgs a) {
-  __shared__ __attribute__((aligned(16))) u64 lds[16 * ROW_LDS];
-  const u32 tid = threadIdx.x, rloc = tid >> 4, t = tid & 15;
-  const u32 rows_per_wg = blockDim.x >> 4;
-  // 1-D grid over (limb i, row block rb, ciphertext b).  Workgroups are dealt round-robin over the 8 XCDs, each with a
-  // private L2: ids that are equal mod 8 share an XCD, so the id is decoded as xcd = id % 8 (low bits of rb), then b
-  // fastest: the ciphertexts of a batch that read the same key rows and twiddles (same i, rb) run back to back on ONE
-  // XCD and share them through its L2 (speed only; any placement is correct).
-  u32 rb, b, i;
-  {
-    const u32 id = blockIdx.x, nb = a.nb, RB = a.rb_count;
-    if ((RB & 7) == 0) {
-      const u32 xcd = id & 7, q = id >> 3;
-      b = q % nb;
-      const u32 rest = q / nb;
-      rb = xcd + 8 * (rest % (RB >> 3));
-      i = rest / (RB >> 3);
-    } else {
-      b = id % nb;
-      rb = (id / nb) % RB;
-      i = id / (nb * RB);
-    }
-  }
-  const u32 row = rb * rows_per_wg + rloc;
-  const u32 nd = a.nd;
-  const u32 m = a.omap[i];
-  const PrimeC P = a.primes[m];
-  const u64 N = 1ull << a.logN;
-  const u64 *__restrict__ tw = a.tw + (u64)m * N;
-  u64 *L = lds + rloc * ROW_LDS;
-  const u32 baseA = (1u << a.logR) + row;
-  const u64 row_off = (u64)row * 256;
-  u64 acc0[16], acc1[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) { acc0[k] = 0; acc1[k] = 0; }
-  for (u32 j = 0; j < nd; ++j) {
-    u64 x[16];
-    if (j == i) {
-      const u64 *s = a.diag + (u64)b * a.diag_bstride + (u64)i * N + row_off;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&s[32 * q + 2 * t]);
-        x[2 * q] = v.x; x[2 * q + 1] = v.y;
-      }
-    } else {
-      const u64 *s = a.t1 + (((u64)b * a.nout + i) * nd + j) * N + row_off;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) x[k] = s[t + 16 * k];
-      fwd_phase<SP, 4>(x, tw, baseA, P);
-#pragma unroll
-      for (int k = 0; k < 16; ++k) L[k * 18 + t] = x[k];
-      wave_lds_sync();
-#pragma unroll
-      for (int k = 0; k < 16; k += 2) {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[t * 18 + k]);
-        x[k] = v.x; x[k + 1] = v.y;
-      }
-      fwd_phase<SP, 4>(x, tw, (baseA << 4) + t, P);
-      wave_lds_sync();
-#pragma unroll
-      for (int k = 0; k < 16; k += 2) *reinterpret_cast<ulonglong2 *>(&L[t * 18 + k]) = make_ulonglong2(x[k], x[k + 1]);
-      wave_lds_sync();
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[(2 * q + (t >> 3)) * 18 + ((2 * t) & 15)]);
-        x[2 * q] = v.x; x[2 * q + 1] = v.y;
-      }
-      wave_lds_sync();
-    }
-    // key MAC in the coalesced layout: lane t owns elements {32q + 2t, 32q + 2t + 1}; x may be lazy (< 4p)
-    const u64 koff = ((u64)j * a.klimbs + m) * N + row_off;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(&a.beta_m[koff + 32 * q + 2 * t]);
-      const ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(&a.alpha_m[koff + 32 * q + 2 * t]);
-      acc0[2 * q] = csub(acc0[2 * q] + mont_mul<SP>(kb.x, x[2 * q], P), P.twop);
-      acc0[2 * q + 1] = csub(acc0[2 * q + 1] + mont_mul<SP>(kb.y, x[2 * q + 1], P), P.twop);
-      acc1[2 * q] = csub(acc1[2 * q] + mont_mul<SP>(ka.x, x[2 * q], P), P.twop);
-      acc1[2 * q + 1] = csub(acc1[2 * q + 1] + mont_mul<SP>(ka.y, x[2 * q + 1], P), P.twop);
-    }
-  }
-  const u64 half = (u64)a.nout * N;
-  u64 *o = a.out + ((u64)b * 2 * a.nout + i) * N + row_off;
-  const u64 *c0 = a.add0 ? a.add0 + (u64)b * a.add_bstride + (u64)i * N + row_off : nullptr;
-  const u64 *c1 = a.add1 ? a.add1 + (u64)b * a.add_bstride + (u64)i * N + row_off : nullptr;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const u32 e = 32 * q + 2 * t;
-    u64 r00 = csub(acc0[2 * q], P.p), r01 = csub(acc0[2 * q + 1], P.p), r10 = csub(acc1[2 * q], P.p), r11 = csub(acc1[2 * q + 1], P.p);
-    if (c0) { const ulonglong2 d0 = *reinterpret_cast<const ulonglong2 *>(&c0[e]); r00 = csub(r00 + d0.x, P.p); r01 = csub(r01 + d0.y, P.p); }
-    if (c1) { const ulonglong2 d1 = *reinterpret_cast<const ulonglong2 *>(&c1[e]); r10 = csub(r10 + d1.x, P.p); r11 = csub(r11 + d1.y, P.p); }
-    *reinterpret_cast<ulonglong2 *>(&o[e]) = make_ulonglong2(r00, r01);
-    *reinterpret_cast<ulonglong2 *>(&o[half + e]) = make_ulonglong2(r10, r11);
-  }
-}
-
-// 8-elements-per-thread, latency-hiding version of relin_rows_mac_kernel (32 threads per row, 8 rows per workgroup; same
-// arguments, grid = nout * (R/8) * nb workgroups of 256 threads).  Vector-memory loads return in issue order (one vmcnt
+// 32 threads per row, 8 elements per thread, up to 8 rows per workgroup; grid = gi * rb_count * nb workgroups.
+// Vector-memory loads return in issue order (one vmcnt
 // counter), so a prefetch only hides latency if everything issued before it is also consumed before it.  Here issue order ==
 // consumption order: inside the key MAC of digit j the kernel requests digit j+1 (when x has been parked in the row image in
 // LDS, from which the MAC reads its operands), then keys_{j+1}[groups 0,1] once MAC groups 0,1 have used keys_j[0,1], then
@@ -773,7 +540,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   __shared__ __attribute__((aligned(16))) u64 lds[8 * ROW8_LDS];
   __shared__ __attribute__((aligned(16))) u64 twl[8 * 256];
   const u32 tid = threadIdx.x, rloc = tid >> 5, t = tid & 31;
-  u32 rb, b, i;
+  u32 rb, b, irel;
   {
     const u32 id = blockIdx.x, nb = a.nb, RB = a.rb_count;
     if ((RB & 7) == 0) {
@@ -781,14 +548,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       b = q % nb;
       const u32 rest = q / nb;
       rb = xcd + 8 * (rest % (RB >> 3));
-      i = rest / (RB >> 3);
+      irel = rest / (RB >> 3);
     } else {
       b = id % nb;
       rb = (id / nb) % RB;
-      i = id / (nb * RB);
+      irel = id / (nb * RB);
     }
   }
-  const u32 row = rb * 8 + rloc;
+  const u32 i = a.i0 + irel;
+  const u32 row = rb * (blockDim.x >> 5) + rloc;  // 8 rows per workgroup (R < 8: all R rows)
   const u32 nd = a.nd;
   const u32 m = a.omap[i];
   const PrimeC P = a.primes[m];
@@ -815,7 +583,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // prefetch stay exact); the diagonal digit is ct[2] limb i itself and skips the NTT
   auto load_digit = [&](u32 j) {
     const u64 *s = (j == i) ? a.diag + (u64)b * a.diag_bstride + (u64)i * N + row_off
-                            : a.t1 + (((u64)b * a.nout + i) * nd + j) * N + row_off;
+                            : a.t1 + (((u64)b * a.gi + irel) * nd + j) * N + row_off;
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] = s[t + 32 * k];
   };

@@ -212,17 +212,3 @@ __global__ __launch_bounds__(PW_THREADS) void to_mont_kernel(u64 *x, const Prime
   const ulonglong2 v = ld2(x + o);
   st2(x + o, to_mont<SP>(v.x, P), to_mont<SP>(v.y, P));
 }
-
-// Decryptor::decrypt lazy loop (src/decryptor.cpp:24-34): out[e][l] = (bx + sx[l]*ax) mod q_l; ct = [e][2][Li][N]
-template <bool SP>
-__global__ __launch_bounds__(PW_THREADS) void decrypt_mac_kernel(u64 *out, const u64 *ct, const u64 *sx, const PrimeC *primes, u32 Li,
-                                                                 u64 N) {
-  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
-  const u32 l = blockIdx.y, e = blockIdx.z;
-  const PrimeC P = primes[l];
-  const u64 in = ((u64)e * 2 * Li + l) * N + d;
-  const ulonglong2 b = ld2(ct + in), a = ld2(ct + in + (u64)Li * N), s = ld2(sx + (u64)l * N + d);
-  st2(out + ((u64)e * Li + l) * N + d, addmod_c(mulmod_full<SP>(s.x, a.x, P), csub(b.x, P.p), P.p),
-      addmod_c(mulmod_full<SP>(s.y, a.y, P), csub(b.y, P.p), P.p));
-}
-

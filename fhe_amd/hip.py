@@ -83,6 +83,7 @@ def load_library():
         "fhe_hip_decrypt": (i, [vp, vp, vp, vp, u32, sz, i]),
         "fhe_hip_encrypt": (i, [vp, vp, vp, vp, vp, vp, vp, u32, sz, i]),
         "fhe_hip_batch_run": (i, [C.POINTER(vp), u32, i, vp, vp, vp, u64, u32, sz, i]),
+        "fhe_hip_set_tuning": (i, [vp, i, u64]),
         "fhe_hip_profile_enable": (i, [vp, i]),
         "fhe_hip_profile_reset": (i, [vp]),
         "fhe_hip_profile_get": (i, [vp, C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double), i]),
@@ -100,9 +101,10 @@ EXPORTED_SYMBOLS = [
     "fhe_hip_mod_up", "fhe_hip_mod_down", "fhe_hip_rescale", "fhe_hip_load_mult_key", "fhe_hip_load_rot_key",
     "fhe_hip_add", "fhe_hip_multiply_plain", "fhe_hip_cross_mult", "fhe_hip_relin_only", "fhe_hip_relinearize",
     "fhe_hip_mul_relin_rescale", "fhe_hip_rotate", "fhe_hip_rotate_non_ntt", "fhe_hip_load_mixed_rot_key", "fhe_hip_rotate_mixed", "fhe_hip_decrypt", "fhe_hip_encrypt", "fhe_hip_profile_enable", "fhe_hip_profile_reset",
-    "fhe_hip_profile_get", "fhe_hip_batch_run", "fhe_hip_conv_to_normal",
+    "fhe_hip_profile_get", "fhe_hip_batch_run", "fhe_hip_conv_to_normal", "fhe_hip_set_tuning",
 ]
 OP_MUL_RELIN_RESCALE, OP_ROTATE, OP_ROTATE_MIXED, OP_ROTATE_NON_NTT = 1, 2, 3, 4
+TUNE_RELIN_GROUP = 1
 
 
 def _buf(x):
@@ -124,6 +126,18 @@ def _same_kind(*bufs):
     if len(set(kinds)) != 1:
         raise TypeError("all buffers of one call must live on the same side (all host or all device)")
     return ptrs, kinds[0]
+
+
+def _count(x):
+    return x.size if isinstance(x, np.ndarray) else x.numel()
+
+
+def _need(**bufs):
+    """name=(buffer, words): the C-ABI takes raw pointers, so every buffer is checked here against the number of 64-bit
+    words the call will touch (a short buffer would be read or written out of bounds by the kernels and copies)."""
+    for name, (x, words) in bufs.items():
+        if _count(x) < words:
+            raise ValueError("%s holds %d words, the call touches %d" % (name, _count(x), words))
 
 
 class HipContext:
@@ -169,39 +183,46 @@ class HipContext:
     def ntt_forward(self, limbs, moduli_idx):
         idx = np.ascontiguousarray(moduli_idx, np.uint32)
         (p,), kind = _same_kind(limbs)
+        _need(limbs=(limbs, idx.size * self.N))
         self._chk(self.lib.fhe_hip_ntt_forward(self.h, p, idx.ctypes.data, idx.size, kind))
         return limbs
 
     def ntt_backward(self, limbs, moduli_idx):
         idx = np.ascontiguousarray(moduli_idx, np.uint32)
         (p,), kind = _same_kind(limbs)
+        _need(limbs=(limbs, idx.size * self.N))
         self._chk(self.lib.fhe_hip_ntt_backward(self.h, p, idx.ctypes.data, idx.size, kind))
         return limbs
 
     # ---- automorphisms ----------------------------------------------------------------------
     def apply_galois(self, polys, nlimbs, galois, batch=1):
         (p,), kind = _same_kind(polys)
+        _need(polys=(polys, batch * nlimbs * self.N))
         self._chk(self.lib.fhe_hip_apply_galois(self.h, p, nlimbs, galois, batch, kind))
         return polys
 
     def apply_galois_non_ntt(self, polys, nlimbs, galois, batch=1):
         (p,), kind = _same_kind(polys)
+        _need(polys=(polys, batch * nlimbs * self.N))
         self._chk(self.lib.fhe_hip_apply_galois_non_ntt(self.h, p, nlimbs, galois, batch, kind))
         return polys
 
     # ---- base converter ---------------------------------------------------------------------
     def mod_up(self, rop, op, Li, batch=1):
         (r, o), kind = _same_kind(rop, op)
+        _need(rop=(rop, batch * (Li + self.K) * self.N), op=(op, batch * Li * self.N))
         self._chk(self.lib.fhe_hip_mod_up(self.h, r, o, Li, batch, kind))
         return rop
 
     def mod_down(self, rop, op, L0, batch=1):
         (r, o), kind = _same_kind(rop, op)
+        _need(rop=(rop, batch * L0 * self.N), op=(op, batch * (L0 + self.K) * self.N))
         self._chk(self.lib.fhe_hip_mod_down(self.h, r, o, L0, batch, kind))
         return rop
 
     def rescale(self, rop, op, n, batch=1):
         (r, o), kind = _same_kind(rop, op)
+        _need(rop=(rop, batch * max(n - 1, 0) * self.N), op=(op, batch * n * self.N))
         self._chk(self.lib.fhe_hip_rescale(self.h, r, o, n, batch, kind))
         return rop
 
@@ -209,78 +230,97 @@ class HipContext:
         """BaseConverter::neg_approx_convert_to_normal_basis for targets 0..L0-1 (src/base_converter.cpp:297-311):
         sp = [batch][K][N] special limbs, power basis -> rop = [batch][L0][N], power basis."""
         (r, o), kind = _same_kind(rop, sp)
+        _need(rop=(rop, batch * L0 * self.N), sp=(sp, batch * self.K * self.N))
         self._chk(self.lib.fhe_hip_conv_to_normal(self.h, r, o, L0, batch, kind))
         return rop
 
     # ---- keys -------------------------------------------------------------------------------
     def load_mult_key(self, beta, alpha):
         (b, a), kind = _same_kind(beta, alpha)
+        _need(beta=(beta, self.L * self.L * self.N), alpha=(alpha, self.L * self.L * self.N))
         self._chk(self.lib.fhe_hip_load_mult_key(self.h, b, a, kind))
 
     def load_rot_key(self, galois, beta, alpha):
         (b, a), kind = _same_kind(beta, alpha)
+        _need(beta=(beta, (self.L + self.K) * self.N), alpha=(alpha, (self.L + self.K) * self.N))
         self._chk(self.lib.fhe_hip_load_rot_key(self.h, galois, b, a, kind))
 
     # ---- evaluator --------------------------------------------------------------------------
     def add(self, rop, op, nlimbs, batch=1):
         (r, o), kind = _same_kind(rop, op)
+        _need(rop=(rop, batch * nlimbs * self.N), op=(op, batch * nlimbs * self.N))
         self._chk(self.lib.fhe_hip_add(self.h, r, o, nlimbs, batch, kind))
         return rop
 
     def multiply_plain(self, ct, pt, nlimbs, batch=1):
         (c, p), kind = _same_kind(ct, pt)
+        _need(ct=(ct, batch * 2 * nlimbs * self.N), pt=(pt, nlimbs * self.N))
         self._chk(self.lib.fhe_hip_multiply_plain(self.h, c, p, nlimbs, batch, kind))
         return ct
 
     def cross_mult(self, out3, c0, c1, Li, batch=1):
         (o, a, b), kind = _same_kind(out3, c0, c1)
+        _need(out3=(out3, batch * 3 * Li * self.N), c0=(c0, batch * 2 * Li * self.N), c1=(c1, batch * 2 * Li * self.N))
         self._chk(self.lib.fhe_hip_cross_mult(self.h, o, a, b, Li, batch, kind))
         return out3
 
     def relin_only(self, out, ct3, Li, batch=1):
         (o, a), kind = _same_kind(out, ct3)
+        _need(out=(out, batch * 2 * Li * self.N), ct3=(ct3, batch * 3 * Li * self.N))
         self._chk(self.lib.fhe_hip_relin_only(self.h, o, a, Li, batch, kind))
         return out
 
     def relinearize(self, out, ct3, Li, batch=1):
         (o, a), kind = _same_kind(out, ct3)
+        _need(out=(out, batch * 2 * max(Li - 1, 0) * self.N), ct3=(ct3, batch * 3 * Li * self.N))
         self._chk(self.lib.fhe_hip_relinearize(self.h, o, a, Li, batch, kind))
         return out
 
     def mul_relin_rescale(self, out, c0, c1, Li, batch=1):
         (o, a, b), kind = _same_kind(out, c0, c1)
+        _need(out=(out, batch * 2 * max(Li - 1, 0) * self.N), c0=(c0, batch * 2 * Li * self.N), c1=(c1, batch * 2 * Li * self.N))
         self._chk(self.lib.fhe_hip_mul_relin_rescale(self.h, o, a, b, Li, batch, kind))
         return out
 
+    def set_tuning(self, knob, value):
+        self._chk(self.lib.fhe_hip_set_tuning(self.h, knob, value))
+
     def rotate(self, galois, ct, Li, batch=1):
         (c,), kind = _same_kind(ct)
+        _need(ct=(ct, batch * 2 * Li * self.N))
         self._chk(self.lib.fhe_hip_rotate(self.h, galois, c, Li, batch, kind))
         return ct
 
     def rotate_non_ntt(self, galois, ct, Li, batch=1):
         """Evaluator::rotate_slots_non_ntt (src/evaluator.cpp:138-146, 327-339, 520-574): ct in the power basis, in place."""
         (c,), kind = _same_kind(ct)
+        _need(ct=(ct, batch * 2 * Li * self.N))
         self._chk(self.lib.fhe_hip_rotate_non_ntt(self.h, galois, c, Li, batch, kind))
         return ct
 
     # ---- MixedRotKey variant (SURVEY §8(f) rank 1) -----------------------------------------
     def load_mixed_rot_key(self, galois, beta, alpha):
         (b, a), kind = _same_kind(beta, alpha)
+        _need(beta=(beta, self.L * (self.L + 1) * self.N), alpha=(alpha, self.L * (self.L + 1) * self.N))
         self._chk(self.lib.fhe_hip_load_mixed_rot_key(self.h, galois, b, a, kind))
 
     def rotate_mixed(self, galois, ct, Li, batch=1):
         (c,), kind = _same_kind(ct)
+        _need(ct=(ct, batch * 2 * Li * self.N))
         self._chk(self.lib.fhe_hip_rotate_mixed(self.h, galois, c, Li, batch, kind))
         return ct
 
     # ---- the steps either side of the path (SURVEY §8(f) rank 3) ----------------------------
     def decrypt(self, out, ct, sx, Li, batch=1):
         (o, c, s), kind = _same_kind(out, ct, sx)
+        _need(out=(out, batch * Li * self.N), ct=(ct, batch * 2 * Li * self.N), sx=(sx, Li * self.N))
         self._chk(self.lib.fhe_hip_decrypt(self.h, o, c, s, Li, batch, kind))
         return out
 
     def encrypt(self, ct, u, e0m, e1, pk_b, pk_a, Li, batch=1):
         ptrs, kind = _same_kind(ct, u, e0m, e1, pk_b, pk_a)
+        pw = batch * Li * self.N
+        _need(ct=(ct, 2 * pw), u=(u, pw), e0m=(e0m, pw), e1=(e1, pw), pk_b=(pk_b, Li * self.N), pk_a=(pk_a, Li * self.N))
         self._chk(self.lib.fhe_hip_encrypt(self.h, *ptrs, Li, batch, kind))
         return ct
 

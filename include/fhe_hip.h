@@ -148,6 +148,13 @@ int fhe_hip_encrypt(fhe_hip_ctx *ctx, uint64_t *ct, const uint64_t *u, const uin
 int fhe_hip_batch_run(fhe_hip_ctx *const *ctxs, uint32_t n_ctx, int op, uint64_t *out, const uint64_t *in0, const uint64_t *in1,
                       uint64_t galois, uint32_t Li, size_t batch, int mem_kind);
 
+/* Runtime tuning (the reference has compile-time constants only, include/fHE/context.hpp:7-14).
+ *   FHE_HIP_TUNE_RELIN_GROUP: output limbs per relinearisation pass (0 = all at once, the default).  The column-pass output
+ *   of the Li^2 digit NTTs is produced and consumed value limbs at a time, which bounds its footprint to
+ *   batch * value * Li * N * 8 bytes; results do not depend on it. */
+#define FHE_HIP_TUNE_RELIN_GROUP 1
+int fhe_hip_set_tuning(fhe_hip_ctx *ctx, int knob, uint64_t value);
+
 /* Measurement support (no reference counterpart): when enabled every kernel launch is bracketed by
  * HIP events on the context's stream; stats are summed per kernel name. */
 int fhe_hip_profile_enable(fhe_hip_ctx *ctx, int on);

@@ -28,6 +28,52 @@ def test_context_creation_rejects_bad_tables():
     big = pr.copy(); big[0] = np.uint64((1 << 62) + 1)
     with pytest.raises(fhe_amd.FheHipError):
         fhe_amd.HipContext(10, 2, 1, big, ps)  # prime >= 2^62
+    dup = pr.copy(); dup[2] = dup[0]
+    dps = ps.copy(); dps[2] = dps[0]
+    with pytest.raises(fhe_amd.FheHipError) as e:
+        fhe_amd.HipContext(10, 2, 1, dup, dps)  # duplicate prime: no inverse modulo itself
+    assert e.value.code == -2
+    # a table whose primes differ by a factor >= 4 breaks the lazy-reduction bound across primes
+    small_p = 12289 * 2048 * 4 + 1  # search a prime = 1 mod 2048 near 2^27
+    while not orc.lib.orc_is_prime(small_p):
+        small_p += 2048
+    x = 2
+    while pow(x, (small_p - 1) // 2, small_p) != small_p - 1:
+        x += 1
+    wide = pr.copy(); wide[2] = np.uint64(small_p)
+    wps = ps.copy(); wps[2] = np.uint64(pow(x, (small_p - 1) >> 11, small_p))
+    with pytest.raises(fhe_amd.FheHipError) as e:
+        fhe_amd.HipContext(10, 2, 1, wide, wps)
+    assert e.value.code == -2
+
+
+def test_mod_up_without_special_primes_copies_the_normal_limbs():
+    pr, ps = orc.gen_primes(10, 3)
+    g = fhe_amd.HipContext(10, 3, 0, pr, ps)
+    x = torch.randint(0, 1 << 60, (2, 3, 1 << 10), dtype=torch.int64, device="cuda")
+    rop = torch.zeros_like(x)
+    g.mod_up(rop, x, 3, batch=2)
+    g.sync()
+    assert torch.equal(rop, x)
+    hx = x.cpu().numpy().view(np.uint64).copy()
+    hr = np.zeros_like(hx)
+    g.mod_up(hr, hx, 3, batch=2)
+    assert np.array_equal(hr, hx)
+
+
+def test_python_binding_checks_buffer_sizes():
+    o, g, pr, ps = _ctx()
+    N = o.N
+    short = torch.zeros((2, N), dtype=torch.int64, device="cuda")
+    with pytest.raises(ValueError):
+        g.ntt_forward(short, [0, 1, 2])           # three limbs asked for, two present
+    rop = torch.zeros((1, 3, N), dtype=torch.int64, device="cuda")
+    with pytest.raises(ValueError):
+        g.mod_up(rop, rop, 3, batch=1)            # rop must hold Li + K limbs
+    out = torch.zeros((1, 2, 2, N), dtype=torch.int64, device="cuda")
+    ct = torch.zeros((1, 2, 3, N), dtype=torch.int64, device="cuda")
+    with pytest.raises(ValueError):
+        g.mul_relin_rescale(out, ct, ct, 3, batch=2)  # batch larger than the buffers
 
 
 def test_empty_batches_are_no_ops_and_keys_are_required():

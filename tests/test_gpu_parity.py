@@ -439,42 +439,6 @@ def test_rotate_mixed_rot_key(logN, L, K, Li, sp):
         g.rotate_mixed(5, d, Li, batch=B)
 
 
-def test_sixteen_element_row_kernels_still_match(tmp_path):
-    """The 16-elements-per-thread forward row pass and fused relinearisation kernel are kept behind FHE_HIP_ROWS8=0 /
-    FHE_HIP_RELIN8=0 (read once per process): run them in a child process against the oracle."""
-    import os, subprocess, sys, textwrap
-    code = textwrap.dedent('''
-        import numpy as np, torch, fhe_amd
-        from oracle import oracle as orc
-        logN, L, K, Li = 12, 3, 1, 3
-        pr, ps = orc.gen_primes(logN, L + K)
-        o, g = orc.Oracle(logN, L, K, pr, ps), fhe_amd.HipContext(logN, L, K, pr, ps)
-        rng = np.random.default_rng(5)
-        poly = lambda: np.stack([rng.integers(0, int(pr[i]), o.N, dtype=np.uint64) for i in range(Li)])
-        x = poly(); idx = list(range(Li))
-        d = torch.from_numpy(x.view(np.int64)).cuda()
-        g.ntt_forward(d, idx)
-        assert np.array_equal(d.cpu().numpy().view(np.uint64), o.ntt_forward(x.copy(), idx))
-        g.ntt_backward(d, idx)
-        assert np.array_equal(d.cpu().numpy().view(np.uint64), x)
-        sx, ext = o.keygen_sk(seed=1)
-        beta, alpha = o.keygen_mult(sx, seed=2)
-        g.load_mult_key(torch.from_numpy(beta.view(np.int64)).cuda(), torch.from_numpy(alpha.view(np.int64)).cuda())
-        c0 = np.stack([poly(), poly()]); c1 = np.stack([poly(), poly()])
-        wb, wa = o.mul_relin_rescale(c0[0], c0[1], c1[0], c1[1], beta, alpha)
-        out = torch.zeros((1, 2, Li - 1, o.N), dtype=torch.int64, device="cuda")
-        g.mul_relin_rescale(out, torch.from_numpy(c0.view(np.int64)).cuda(), torch.from_numpy(c1.view(np.int64)).cuda(), Li, batch=1)
-        h = out.cpu().numpy().view(np.uint64)
-        assert np.array_equal(h[0, 0], wb) and np.array_equal(h[0, 1], wa)
-        print("legacy kernels OK")
-    ''')
-    env = dict(os.environ, FHE_HIP_ROWS8="0", FHE_HIP_RELIN8="0", FHE_HIP_ROWS8_INV="0")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
-    assert r.returncode == 0 and "legacy kernels OK" in r.stdout, r.stdout + r.stderr
-
-
 def _uniform(o, idx, rng):
     return np.stack([rng.integers(0, int(o.primes[i]), o.N, dtype=np.uint64) for i in idx])
 
@@ -555,3 +519,26 @@ def test_shape_sweep_relin_and_rotate(logN, L, K, Li, B):
     for b in range(B):
         wb, wa = o.rotate_mixed(c1[b, 0], c1[b, 1], gal, mb, ma)
         assert np.array_equal(h[b, 0], wb) and np.array_equal(h[b, 1], wa)
+
+
+@pytest.mark.parametrize("logN,L,Li,group", [(12, 5, 5, 1), (12, 5, 4, 2), (13, 4, 4, 3), (10, 3, 3, 7)])
+def test_relinearisation_in_groups_of_output_limbs(logN, L, Li, group):
+    """FHE_HIP_TUNE_RELIN_GROUP: the column-pass output is produced and consumed `group` output limbs at a time; results
+    must not depend on it (fhe_hip_set_tuning, include/fhe_hip.h)."""
+    o, g = ctx_pair(logN, L, 1)
+    sx, ext = o.keygen_sk(seed=900 + logN)
+    beta, alpha = o.keygen_mult(sx, seed=901)
+    g.load_mult_key(dev(beta), dev(alpha))
+    B = 2
+    c0 = np.stack([np.stack([rand_poly(o, range(Li), 910 + 4 * b), rand_poly(o, range(Li), 911 + 4 * b)]) for b in range(B)])
+    c1 = np.stack([np.stack([rand_poly(o, range(Li), 912 + 4 * b), rand_poly(o, range(Li), 913 + 4 * b)]) for b in range(B)])
+    want = np.stack([np.stack(o.mul_relin_rescale(c0[b, 0], c0[b, 1], c1[b, 0], c1[b, 1], beta, alpha)) for b in range(B)])
+    try:
+        g.set_tuning(fhe_amd.hip.TUNE_RELIN_GROUP, group)
+        out = torch.zeros((B, 2, Li - 1, o.N), dtype=torch.int64, device="cuda")
+        g.mul_relin_rescale(out, dev(c0), dev(c1), Li, batch=B)
+        assert np.array_equal(host(out), want)
+    finally:
+        g.set_tuning(fhe_amd.hip.TUNE_RELIN_GROUP, 0)
+    with pytest.raises(fhe_amd.FheHipError):
+        g.set_tuning(99, 1)

@@ -3,7 +3,7 @@
 import collections, re, sys
 s = open(sys.argv[1]).read()
 pat = sys.argv[2] if len(sys.argv) > 2 else ""
-for m in re.finditer(r'^(_Z\w+):[^\n]*\n(.*?)s_endpgm', s, re.S | re.M):
+for m in re.finditer(r'^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end', s, re.S | re.M):
     name, body = m.group(1), m.group(2)
     if pat not in name:
         continue
