@@ -19,6 +19,11 @@ static thread_local std::string g_create_error;
 // no exception crosses the C ABI (std::bad_alloc from the host-side containers is the only realistic one)
 static int abi_exception() { try { g_create_error = "C++ exception inside the library (out of host memory?)"; } catch (...) {} return FHE_HIP_ERR_HIP; }
 
+// Scratch of the entry points that allocate nothing (include/fhe_hip.h: fhe_hip_mul_relin_rescale_noalloc).  One copy per GPU
+// the code object is loaded on, held until the process ends.  In host code this name is only a handle for
+// hipGetSymbolAddress (fhe_hip_ctx_create, once per context with its device current); kernels receive the address it returns.
+static __device__ __align__(256) unsigned char fhe_hip_scratch[FHE_HIP_NOALLOC_SCRATCH_BYTES];
+
 namespace {
 
 struct RotKeyDev {
@@ -67,6 +72,10 @@ struct fhe_hip_ctx {
   // workspaces (grow-only)
   void *ws[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t ws_bytes[6] = {0, 0, 0, 0, 0, 0};
+  // entry points that allocate nothing carve their workspaces out of this device's copy of the static scratch array
+  // instead (fixed_ws set for the duration of such a call; fixed_used = bytes carved so far)
+  unsigned char *scratch = nullptr;
+  bool fixed_ws = false; size_t fixed_used = 0;
   uint32_t relin_group = 0;  // output limbs per relinearisation pass (0 = all Li at once): fhe_hip_set_tuning
   void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[4] = {0, 0, 0, 0};
@@ -127,6 +136,15 @@ int upload(fhe_hip_ctx *c, T **dst, const std::vector<T> &v) {
 
 int ensure_ws(fhe_hip_ctx *c, int slot, size_t bytes) {
   if (c->ws_bytes[slot] >= bytes) return FHE_HIP_OK;
+  if (c->fixed_ws) {  // no allocation: carve from the static scratch array (slots are fresh for every such call)
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (c->ws[slot] || need > (size_t)FHE_HIP_NOALLOC_SCRATCH_BYTES - c->fixed_used)
+      FAIL(c, FHE_HIP_ERR_RANGE, "operands too large for the fixed scratch buffer of the entry points that allocate nothing (FHE_HIP_NOALLOC_SCRATCH_BYTES)");
+    c->ws[slot] = c->scratch + c->fixed_used;
+    c->ws_bytes[slot] = bytes;
+    c->fixed_used += need;
+    return FHE_HIP_OK;
+  }
   if (c->ws[slot]) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->ws[slot])); c->ws[slot] = nullptr; c->ws_bytes[slot] = 0; }
   HIPCHK(c, hipMalloc(&c->ws[slot], bytes));
   c->ws_bytes[slot] = bytes;
@@ -174,9 +192,9 @@ inline hipEvent_t prof_event(fhe_hip_ctx *c) {
 #define LAUNCH(c, name, kern, grid, block, ...)                                                  \
   do {                                                                                           \
     hipEvent_t ev0_ = nullptr;                                                                   \
-    if ((c)->prof) ev0_ = (c)->chain_valid ? (c)->chain_ev : prof_event(c);                      \
+    if ((c)->prof && !(c)->fixed_ws) ev0_ = (c)->chain_valid ? (c)->chain_ev : prof_event(c);                      \
     hipLaunchKernelGGL(kern, grid, block, 0, (c)->stream, __VA_ARGS__);                          \
-    if ((c)->prof) {                                                                             \
+    if ((c)->prof && !(c)->fixed_ws) {                                                           \
       (c)->chain_ev = prof_event(c); (c)->chain_valid = true;                                    \
       prof_entry((c), name)->pending.push_back({ev0_, (c)->chain_ev});                           \
     }                                                                                            \
@@ -415,7 +433,15 @@ int dev_relin(fhe_hip_ctx *c, u64 *out, const u64 *ct3, u32 Li, u32 batch) {
   if (!c->d_mk_beta) FAIL(c, FHE_HIP_ERR_NOKEY, "mult key not loaded");
   u32 group = c->relin_group ? (c->relin_group < Li ? c->relin_group : Li) : Li;
   u32 chunk = batch;
-  {
+  if (c->fixed_ws) {
+    // everything has to fit what is left of the fixed scratch buffer: whole batch at once, the largest group that fits
+    const size_t left = (size_t)FHE_HIP_NOALLOC_SCRATCH_BYTES - c->fixed_used, limb = (size_t)N * 8 + 256;
+    const size_t pw_limbs = (size_t)batch * Li;
+    if (left / limb <= pw_limbs) FAIL(c, FHE_HIP_ERR_RANGE, "operands too large for the fixed scratch buffer (FHE_HIP_NOALLOC_SCRATCH_BYTES)");
+    const size_t g = (left / limb - pw_limbs) / ((size_t)batch * Li);
+    if (g < 1) FAIL(c, FHE_HIP_ERR_RANGE, "operands too large for the fixed scratch buffer (FHE_HIP_NOALLOC_SCRATCH_BYTES)");
+    if (g < group) group = (u32)g;
+  } else {
     // bound the intermediate: process the batch in chunks of at most 8 GiB
     const size_t per_ct = (size_t)group * Li * N * 8;
     chunk = (u32)((8ull << 30) / per_ct);
@@ -660,6 +686,13 @@ int fhe_hip_ctx_create(fhe_hip_ctx **out, uint32_t logN, uint32_t L, uint32_t K,
         if (primes[k] == primes[m]) { c->err = "duplicate prime in the table"; return fail(FHE_HIP_ERR_RANGE); }
     }
     if (pmax / 4 >= pmin) { c->err = "primes of one table must satisfy max(p) < 4 * min(p) (lazy reduction across primes)"; return fail(FHE_HIP_ERR_RANGE); }
+  }
+  {
+    // this device's copy of the static scratch array (entry points that allocate nothing); the array's name is only a handle here
+    void *sp = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&sp, HIP_SYMBOL(fhe_hip_scratch));
+    if (e != hipSuccess || !sp) { c->err = std::string("hipGetSymbolAddress(fhe_hip_scratch): ") + hipGetErrorString(e); return fail(FHE_HIP_ERR_HIP); }
+    c->scratch = (unsigned char *)sp;
   }
   std::vector<PrimeC> pc(M);
   std::vector<u64> twf((size_t)M * N), twi((size_t)M * N);
@@ -1012,6 +1045,30 @@ int fhe_hip_mul_relin_rescale(fhe_hip_ctx *c, uint64_t *out, const uint64_t *c0,
   TRY(dev_mul_relin_rescale(c, dout, d0, d1, Li, (u32)batch));
   return st.finish();
   } catch (...) { return abi_exception(); }
+}
+
+// fhe_hip_mul_relin_rescale for callers that cannot allocate: same kernels, every workspace carved out of this device's copy
+// of fhe_hip_scratch (address taken in fhe_hip_ctx_create).  Calls no hipMalloc / hipFree / event creation; device pointers only.
+int fhe_hip_mul_relin_rescale_noalloc(fhe_hip_ctx *c, uint64_t *out, const uint64_t *c0, const uint64_t *c1, uint32_t Li, size_t batch) {
+  if (!c) return FHE_HIP_ERR_ARG;
+  TRY(check_ctx(c));
+  if (!out || !c0 || !c1) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  TRY(check_li(c, Li, 2));
+  if (batch == 0) return FHE_HIP_OK;
+  if (!c->d_mk_beta) FAIL(c, FHE_HIP_ERR_NOKEY, "mult key not loaded");
+  // workspaces besides the relinearisation's own: ct3 (3 Li limbs) + relinearised ct (2 Li) + rescale tails (2 (Li-1)) per op;
+  // dev_relin adds the power-basis digits (Li) and at least one group of column-pass output (Li)
+  const size_t limb = (size_t)c->N * 8;
+  if (batch > (size_t)FHE_HIP_NOALLOC_SCRATCH_BYTES / ((size_t)(9 * Li - 2) * limb))
+    FAIL(c, FHE_HIP_ERR_RANGE, "batch * (9 Li - 2) * N * 8 bytes exceeds FHE_HIP_NOALLOC_SCRATCH_BYTES: split the batch");
+  // the grow-only workspaces of the allocating entry points are set aside for the duration of this call
+  void *saved_ws[6]; size_t saved_bytes[6];
+  for (int k = 0; k < 6; ++k) { saved_ws[k] = c->ws[k]; saved_bytes[k] = c->ws_bytes[k]; c->ws[k] = nullptr; c->ws_bytes[k] = 0; }
+  c->fixed_ws = true; c->fixed_used = 0;
+  const int rc = dev_mul_relin_rescale(c, (u64 *)out, (const u64 *)c0, (const u64 *)c1, Li, (u32)batch);
+  c->fixed_ws = false;
+  for (int k = 0; k < 6; ++k) { c->ws[k] = saved_ws[k]; c->ws_bytes[k] = saved_bytes[k]; }
+  return rc;
 }
 
 int fhe_hip_set_tuning(fhe_hip_ctx *c, int knob, uint64_t value) {

@@ -83,6 +83,7 @@ def load_library():
         "fhe_hip_decrypt": (i, [vp, vp, vp, vp, u32, sz, i]),
         "fhe_hip_encrypt": (i, [vp, vp, vp, vp, vp, vp, vp, u32, sz, i]),
         "fhe_hip_batch_run": (i, [C.POINTER(vp), u32, i, vp, vp, vp, u64, u32, sz, i]),
+        "fhe_hip_mul_relin_rescale_noalloc": (i, [vp, vp, vp, vp, u32, sz]),
         "fhe_hip_set_tuning": (i, [vp, i, u64]),
         "fhe_hip_profile_enable": (i, [vp, i]),
         "fhe_hip_profile_reset": (i, [vp]),
@@ -101,10 +102,11 @@ EXPORTED_SYMBOLS = [
     "fhe_hip_mod_up", "fhe_hip_mod_down", "fhe_hip_rescale", "fhe_hip_load_mult_key", "fhe_hip_load_rot_key",
     "fhe_hip_add", "fhe_hip_multiply_plain", "fhe_hip_cross_mult", "fhe_hip_relin_only", "fhe_hip_relinearize",
     "fhe_hip_mul_relin_rescale", "fhe_hip_rotate", "fhe_hip_rotate_non_ntt", "fhe_hip_load_mixed_rot_key", "fhe_hip_rotate_mixed", "fhe_hip_decrypt", "fhe_hip_encrypt", "fhe_hip_profile_enable", "fhe_hip_profile_reset",
-    "fhe_hip_profile_get", "fhe_hip_batch_run", "fhe_hip_conv_to_normal", "fhe_hip_set_tuning",
+    "fhe_hip_profile_get", "fhe_hip_batch_run", "fhe_hip_conv_to_normal", "fhe_hip_mul_relin_rescale_noalloc", "fhe_hip_set_tuning",
 ]
 OP_MUL_RELIN_RESCALE, OP_ROTATE, OP_ROTATE_MIXED, OP_ROTATE_NON_NTT = 1, 2, 3, 4
 TUNE_RELIN_GROUP = 1
+NOALLOC_SCRATCH_BYTES = 256 << 20
 
 
 def _buf(x):
@@ -280,6 +282,16 @@ class HipContext:
         (o, a, b), kind = _same_kind(out, c0, c1)
         _need(out=(out, batch * 2 * max(Li - 1, 0) * self.N), c0=(c0, batch * 2 * Li * self.N), c1=(c1, batch * 2 * Li * self.N))
         self._chk(self.lib.fhe_hip_mul_relin_rescale(self.h, o, a, b, Li, batch, kind))
+        return out
+
+    def mul_relin_rescale_noalloc(self, out, c0, c1, Li, batch=1):
+        """fhe_hip_mul_relin_rescale_noalloc: same result, device buffers only, workspaces in the library's static scratch
+        array (no allocation of any kind inside the call)."""
+        (o, a, b), kind = _same_kind(out, c0, c1)
+        if kind != MEM_DEVICE:
+            raise TypeError("the no-alloc entry point takes device buffers only")
+        _need(out=(out, batch * 2 * max(Li - 1, 0) * self.N), c0=(c0, batch * 2 * Li * self.N), c1=(c1, batch * 2 * Li * self.N))
+        self._chk(self.lib.fhe_hip_mul_relin_rescale_noalloc(self.h, o, a, b, Li, batch))
         return out
 
     def set_tuning(self, knob, value):

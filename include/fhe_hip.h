@@ -148,6 +148,17 @@ int fhe_hip_encrypt(fhe_hip_ctx *ctx, uint64_t *ct, const uint64_t *u, const uin
 int fhe_hip_batch_run(fhe_hip_ctx *const *ctxs, uint32_t n_ctx, int op, uint64_t *out, const uint64_t *in0, const uint64_t *in1,
                       uint64_t galois, uint32_t Li, size_t batch, int mem_kind);
 
+/* fhe_hip_mul_relin_rescale for callers that cannot allocate.  No counterpart in the reference (a CPU library with no device
+ * memory); it exists for callers that cannot call hipMalloc: code under HIP graph capture, tight serving loops, harnesses
+ * that forbid allocation.  Same kernels and results as fhe_hip_mul_relin_rescale, device pointers only; every workspace is
+ * carved out of a static device array of FHE_HIP_NOALLOC_SCRATCH_BYTES that each GPU the library runs on holds until the
+ * process ends.  The call performs no hipMalloc / hipFree / event creation.  Needs batch * (9 Li - 2) * N * 8 bytes of scratch
+ * (N = 2^16, Li = 30: 1 op per call; N = 2^15, Li = 16: 7 ops); larger requests fail with FHE_HIP_ERR_RANGE and no side
+ * effect.  Every call on a GPU, from any context, uses that GPU's one array: calls that overlap in time on one GPU race;
+ * serialise them (one stream, or events between streams). */
+#define FHE_HIP_NOALLOC_SCRATCH_BYTES (256u << 20)
+int fhe_hip_mul_relin_rescale_noalloc(fhe_hip_ctx *ctx, uint64_t *out, const uint64_t *c0, const uint64_t *c1, uint32_t Li, size_t batch);
+
 /* Runtime tuning (the reference has compile-time constants only, include/fHE/context.hpp:7-14).
  *   FHE_HIP_TUNE_RELIN_GROUP: output limbs per relinearisation pass (0 = all at once, the default).  The column-pass output
  *   of the Li^2 digit NTTs is produced and consumed value limbs at a time, which bounds its footprint to
