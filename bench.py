@@ -10,14 +10,25 @@ A "step" is one pass of the hot path over one batch of synthetic, HBM-resident i
   --workload c5  N=2^15, Li=16 multiply+relin+rescale
   --workload rotm | rotnn | dec | enc   the SURVEY 8(f) rows: MixedRotKey rotation, power-basis rotation, decrypt and encrypt
                  inner loops (N=2^16, Li=30); their `roofline` is the whole pipeline against the op's algorithmic bytes
-Before the W warmup steps the steps run untimed for --prewarm seconds (clock ramp).
-One rank per GPU (torch.distributed / RCCL is used only for the barrier and the max-over-ranks of the time:
-independent ciphertexts shard with no data-path collective -> "scaling": "weak").
+Before the W warmup steps the steps run untimed for --prewarm seconds (clock ramp).  The K timed steps
+run with the library's per-launch events OFF; the per-kernel durations (`kernel_ms`, `roofline`) come from a second, untimed
+pass of the same steps with the events on.  The default (c3) run also carries `ntt_n16`: 2048 forward limb-NTTs at N=2^16,
+so that BASELINE.json's other headline figure (limb-NTTs/sec) is on the driver's line too.
+
+One rank per GPU.  `--gpus N` (N > 1) without a torch.distributed launcher starts N child processes of this script itself,
+before anything touches the GPU; under `python -m torch.distributed.run` it reads RANK / LOCAL_RANK / WORLD_SIZE and must
+agree with --gpus.  Independent ciphertexts shard with no data-path collective ("scaling": "weak"); RCCL carries the barrier,
+the max-over-ranks of the time, the key broadcast and, after the timed region, one operation per rank to rank 0, which
+recomputes it on its own GPU and requires byte equality (`rccl_parity`).  `--e2e` adds the end-to-end figure of SURVEY 8(e):
+the same operations with inputs and results resident on rank 0 only, through fhe_amd.batching.ShardedEvaluator
+(chunked star scatter / gather over RCCL).
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +38,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SIMD = 256 * 4       # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs
+VALU_ISSUE_CYCLES = 4  # cycles one wave64 multiply-add / 64-bit / carry instruction holds a SIMD's issue port
 
 WORKLOADS = {
     #        logN  L   K   Li  default batch
@@ -42,6 +55,7 @@ WORKLOADS = {
     "enc": (16, 30, 1, 30, 64),     # rank 3: encrypt inner loops
 }
 GENERIC = ("rotm", "rotnn", "dec", "enc")
+MULT = ("c3", "c5")
 
 
 def gen_primes_host(logN, count):
@@ -86,7 +100,7 @@ def gen_primes_host(logN, count):
 
 def algorithmic_bytes(workload, N, Li, K):
     """SURVEY.md §8(d) per-unit algorithmic bytes (8-byte limbs)."""
-    if workload in ("c3", "c5"):
+    if workload in MULT:
         return 8 * N * (2 * Li * Li + 6 * Li - 2)
     if workload in ("c4", "rotnn"):
         return 8 * N * (6 * Li + 2 * K)
@@ -99,15 +113,31 @@ def algorithmic_bytes(workload, N, Li, K):
     return 16 * N  # one limb-NTT
 
 
+def dominant_kernel_bytes(workload, N, Li, K, units_per_launch):
+    """Algorithmic HBM bytes ONE launch of the workload's dominant kernel has to move, and the same
+    figure with the key limbs charged to every ciphertext of the batch (`per_op_keys`, SURVEY 8(d)'s per-op convention).
+    c3 / c5, relin_rows8p_mac_kernel: the 2*Li^2 key limbs ONCE per launch (the ciphertexts of a batch share them through
+    L2, and the counters confirm they are fetched once), per ciphertext the Li^2 digit limbs (column-pass output + diagonal),
+    2*Li addend limbs in and 2*Li result limbs out."""
+    if workload in MULT:
+        shared = 8 * N * (2 * Li * Li + units_per_launch * (Li * Li + 4 * Li))
+        per_op = 8 * N * units_per_launch * (2 * Li * Li + Li * Li + 4 * Li)
+        return shared, per_op
+    if workload == "c4":    # the three base conversions of a rotation: Li (or K) limbs in, K (or Li) limbs out each
+        b = units_per_launch * 8 * N * (Li + K)
+        return b, b
+    b = units_per_launch * 16 * N  # ntt / c2: the cols + rows pair is one limb-NTT = read N + write N words
+    return b, b
+
+
 def cpu_baseline(workload, logN, L, K, Li, inputs, budget_s=20.0):
     """Times the CPU oracle (kind "port": restatement of the reference's loop structure) on rank 0's host cores,
     single thread like the reference, on a bounded sample of the same workload."""
     from oracle import oracle as orc
     pr, ps = inputs["primes"], inputs["psi"]
     o = orc.Oracle(logN, L, K, pr, ps)
-    N = 1 << logN
     t_used, units = 0.0, 0
-    if workload in ("c3", "c5"):
+    if workload in MULT:
         c0, c1, beta, alpha = inputs["c0"], inputs["c1"], inputs["beta"], inputs["alpha"]
         while t_used < budget_s and units < c0.shape[0]:
             t0 = time.perf_counter()
@@ -149,7 +179,7 @@ def cpu_baseline(workload, logN, L, K, Li, inputs, budget_s=20.0):
         from concurrent.futures import ThreadPoolExecutor
         T = max(1, min(16, os.cpu_count() or 1))
         per_unit = t_used / max(units, 1)
-        if workload in ("c3", "c5"):
+        if workload in MULT:
             one = lambda i: o.mul_relin_rescale(c0[0, 0], c0[0, 1], c1[0, 0], c1[0, 1], beta, alpha)  # noqa: E731
             reps = max(1, int(min(budget_s / 2, 10.0) / per_unit))
         elif workload in GENERIC:
@@ -163,6 +193,7 @@ def cpu_baseline(workload, logN, L, K, Li, inputs, budget_s=20.0):
             one = lambda i: o.ntt_forward(x[:nn].copy(), idx[:nn])  # noqa: E731
             per_unit = per_unit * nn
             reps = max(1, int(5.0 / per_unit))
+
         def worker(i):
             for _ in range(reps):
                 one(i)
@@ -178,6 +209,227 @@ def cpu_baseline(workload, logN, L, K, Li, inputs, budget_s=20.0):
     return res
 
 
+def verify_over_collective(sb, compute, c0_one, c1_one, out_one, in_shape, out_shape):
+    """After the timed region of a multi-rank run: every rank contributes ONE operation (its inputs and the result its GPU
+    produced) to rank 0 through ShardedBatch.gather (RCCL on GPUs); rank 0 recomputes all of them on its own device and
+    requires byte equality.  Returns (parity, ranks_seen) on rank 0, (None, None) elsewhere.  compute(c0, c1, n) -> out."""
+    import torch
+    n = sb.world
+    g0 = sb.gather(c0_one, n, in_shape)
+    g1 = sb.gather(c1_one, n, in_shape)
+    go = sb.gather(out_one, n, out_shape)
+    if sb.rank != sb.root:
+        return None, None
+    want = compute(g0, g1, n)
+    rows_ok = [bool(torch.equal(want[r], go[r])) for r in range(n)]
+    # a rank whose transfer never arrived leaves its slot of the gather buffer unequal to the recomputation
+    return all(rows_ok), sum(rows_ok)
+
+
+def launch_ranks(n):
+    """`--gpus N` without a launcher: N fresh children of this script, one per GPU, started before this process has made any
+    GPU call (it makes none afterwards either); rank 0's stdout is this process's."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    return next((rc for rc in rcs if rc), 0)
+
+
+def read_profile_json(kind, workload):
+    path = os.path.join(ROOT, "profiles", "%s_%s.json" % (kind, workload))
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
+
+
+class Setup:
+    """One workload on one context: synthetic HBM-resident inputs and the step() that runs the hot path over them."""
+
+    def __init__(self, workload, B, local_rank, rank, sb=None, relin_group=0):
+        import torch
+        import fhe_amd
+        self.workload = workload
+        self.logN, self.L, self.K, self.Li, dflt = WORKLOADS[workload]
+        self.B = B or dflt
+        logN, L, K, Li, B = self.logN, self.L, self.K, self.Li, self.B
+        self.N = N = 1 << logN
+        self.primes, self.psi = gen_primes_host(logN, L + K)
+        self.ctx = ctx = fhe_amd.HipContext(logN, L, K, self.primes, self.psi, device=local_rank)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        if relin_group:
+            ctx.set_tuning(fhe_amd.hip.TUNE_RELIN_GROUP, relin_group)
+        gen = torch.Generator(device="cuda").manual_seed(0x5EED0000 + rank)
+
+        def rnd(*shape):  # uniform residues below 2^61 (< every prime of the table)
+            return torch.randint(0, 1 << 61, shape, dtype=torch.int64, device="cuda", generator=gen)
+
+        def key(*shape):  # key material is replicated: rank 0 draws it, RCCL broadcasts it once
+            t = rnd(*shape)
+            if sb is not None:
+                sb.broadcast(t)
+            return t
+        self.rnd = rnd
+        self.inputs = {"primes": self.primes, "psi": self.psi}
+        self.per_step_units = B
+        host = lambda t: t.cpu().numpy().view(np.uint64)  # noqa: E731
+        if workload in MULT:
+            self.c0, self.c1 = rnd(B, 2, Li, N), rnd(B, 2, Li, N)
+            self.beta, self.alpha = key(L, L, N), key(L, L, N)
+            self.out = torch.empty((B, 2, Li - 1, N), dtype=torch.int64, device="cuda")
+            ctx.load_mult_key(self.beta, self.alpha)
+            self.step = lambda: ctx.mul_relin_rescale(self.out, self.c0, self.c1, Li, batch=B)
+            self.metric, self.unit = "ct-mult+relin+rescale/sec at N=2^%d, Li=%d" % (logN, Li), "ops/s"
+        elif workload == "c4":
+            self.ct = rnd(B, 2, Li, N)
+            self.rkb, self.rka = key(L + K, N), key(L + K, N)
+            self.galois = 3
+            ctx.load_rot_key(self.galois, self.rkb, self.rka)
+            self.work = self.ct.clone()
+            self.step = lambda: ctx.rotate(self.galois, self.work, Li, batch=B)
+            self.metric, self.unit = "rotation-keyswitch/sec at N=2^%d, Li=K=%d" % (logN, Li), "ops/s"
+        elif workload in GENERIC:
+            galois = 3
+            if workload in ("rotm", "rotnn"):
+                ct = rnd(B, 2, Li, N)
+                work = ct.clone()
+                if workload == "rotm":
+                    kb, ka = key(L, L + 1, N), key(L, L + 1, N)
+                    ctx.load_mixed_rot_key(galois, kb, ka)
+                    self.step = lambda: ctx.rotate_mixed(galois, work, Li, batch=B)
+                    self.metric = "MixedRotKey rotation-keyswitch/sec at N=2^%d, Li=%d" % (logN, Li)
+                    self.inputs["cpu_one"] = lambda o: (lambda i, c=host(ct[:1]), b=host(kb), a=host(ka): o.rotate_mixed(c[0, 0], c[0, 1], galois, b, a))
+                else:
+                    kb, ka = key(L + K, N), key(L + K, N)
+                    ctx.load_rot_key(galois, kb, ka)
+                    self.step = lambda: ctx.rotate_non_ntt(galois, work, Li, batch=B)
+                    self.metric = "power-basis rotation-keyswitch/sec at N=2^%d, Li=K=%d" % (logN, Li)
+                    self.inputs["cpu_one"] = lambda o: (lambda i, c=host(ct[:1]), b=host(kb), a=host(ka): o.rotate_non_ntt(c[0, 0], c[0, 1], galois, b, a))
+            elif workload == "dec":
+                ct, sx = rnd(B, 2, Li, N), key(L, N)
+                out = torch.empty((B, Li, N), dtype=torch.int64, device="cuda")
+                self.step = lambda: ctx.decrypt(out, ct, sx, Li, batch=B)
+                self.metric = "decrypt (bx + sx*ax, INTT)/sec at N=2^%d, Li=%d" % (logN, Li)
+                self.inputs["cpu_one"] = lambda o: (lambda i, c=host(ct[:1]), s_=host(sx): o.decrypt(c[0, 0], c[0, 1], s_))
+            else:
+                u, e0m, e1 = rnd(B, Li, N), rnd(B, Li, N), rnd(B, Li, N)
+                pkb, pka = key(L, N), key(L, N)
+                out = torch.empty((B, 2, Li, N), dtype=torch.int64, device="cuda")
+                self.step = lambda: ctx.encrypt(out, u, e0m, e1, pkb, pka, Li, batch=B)
+                self.metric = "encrypt (NTT, u*pk + e)/sec at N=2^%d, Li=%d" % (logN, Li)
+                self.inputs["cpu_one"] = lambda o: (lambda i, a_=host(u[:1]), b_=host(e0m[:1]), c_=host(e1[:1]), p_=host(pkb), q_=host(pka):
+                                                    o.encrypt_core(a_[0], b_[0], c_[0], p_, q_))
+            self.unit = "ops/s"
+            self.inputs["cpu_unit"] = self.unit
+        else:
+            self.x = rnd(B, N)
+            self.idx = np.tile(np.arange(L, dtype=np.uint32), (B + L - 1) // L)[:B]
+            if workload == "c2":
+                def step():
+                    ctx.ntt_forward(self.x, self.idx)
+                    ctx.ntt_backward(self.x, self.idx)
+                self.step = step
+                self.per_step_units = 2 * B
+            else:
+                self.step = lambda: ctx.ntt_forward(self.x, self.idx)
+            self.metric, self.unit = "limb-NTTs/sec at N=2^%d" % logN, "limb-NTT/s"
+
+    def timed(self, steps, warmup, prewarm, barrier):
+        """(elapsed seconds of `steps` steps with the library's events off, per-kernel profile of a second untimed pass)."""
+        import torch
+        ctx = self.ctx
+        ctx.profile_enable(False)
+        t_end = time.perf_counter() + max(0.0, prewarm)
+        while time.perf_counter() < t_end:  # untimed: clock ramp (see --prewarm)
+            for _ in range(4):
+                self.step()
+            torch.cuda.synchronize()
+        for _ in range(warmup):
+            self.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # per-kernel durations: same steps again, untimed, with HIP events recorded on the launch stream around every launch
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        prof = ctx.profile_get()
+        ctx.profile_enable(False)
+        return elapsed, prof
+
+    def roofline(self, prof, steps):
+        """`roofline` (HBM) and `roofline_valu` blocks for the workload's dominant kernel."""
+        w, N, Li, K, B = self.workload, self.N, self.Li, self.K, self.B
+        kms = lambda name: prof.get(name, (0, 0.0))  # noqa: E731
+        if w in MULT:
+            launches, ms = kms("relin_rows_mac")
+            kname = "relin_rows8p_mac_kernel"
+            units_per_launch = B
+        elif w in GENERIC:  # the "next" rows: the whole pipeline of the op against its algorithmic bytes
+            launches, ms = steps, sum(v[1] for v in prof.values())
+            kname = "whole pipeline: " + " + ".join(sorted(prof))
+            units_per_launch = B
+        elif w == "c4":
+            launches = kms("bconv_modup")[0] + kms("bconv_moddown")[0]
+            ms = kms("bconv_modup")[1] + kms("bconv_moddown")[1]
+            kname = "bconv_kernel (mod-up + 2x mod-down)"
+            units_per_launch = B
+        else:
+            launches = kms("ntt_fwd_cols")[0]
+            ms = kms("ntt_fwd_cols")[1] + kms("ntt_fwd_rows")[1]
+            kname = "ntt_fwd (ntt_cols_kernel + ntt_rows8_fwd_kernel pair)"
+            units_per_launch = B
+        if not launches or ms <= 0:
+            return None, None
+        avg_ms = ms / launches
+        if w in GENERIC:
+            alg = per_op = units_per_launch * algorithmic_bytes(w, N, Li, K)
+        else:
+            alg, per_op = dominant_kernel_bytes(w, N, Li, K, units_per_launch)
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        default_batch = self.B == WORKLOADS[w][4]
+        tj = read_profile_json("traffic", w) if default_batch else None
+        traffic = tj.get("hbm_bytes_per_launch") if tj else None
+        roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "alg_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches": launches}
+        if traffic:
+            roof["traffic_frac"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if per_op != alg:
+            roof["per_op_keys"] = {"alg_bytes_per_launch": per_op, "achieved": per_op / (avg_ms * 1e-3) / 1e9,
+                                   "frac": per_op / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "note": "SURVEY 8(d) per-op convention: the 2*Li^2 key limbs charged to every ciphertext of the batch; "
+                                           "the counters show they are fetched once per launch, so this is not HBM traffic"}
+        # VALU issue: committed PMC pass (profiles/valu_<workload>.json: SQ_INSTS_VALU and GRBM_GUI_ACTIVE of this kernel)
+        valu = None
+        vj = read_profile_json("valu", w) if default_batch else None
+        if vj and vj.get("insts_valu_per_launch") and vj.get("gui_active_per_xcd_per_launch") and vj.get("launch_ms_in_pmc_pass"):
+            slots = vj["insts_valu_per_launch"] * VALU_ISSUE_CYCLES / N_SIMD    # issue cycles per SIMD the launch needs
+            sclk_mhz = vj["gui_active_per_xcd_per_launch"] / (vj["launch_ms_in_pmc_pass"] * 1e3)
+            live = slots / (sclk_mhz * 1e3 * avg_ms)
+            valu = {"bound": "valu-issue", "kernel": kname, "insts_valu_per_launch": vj["insts_valu_per_launch"],
+                    "issue_cycles_per_inst": VALU_ISSUE_CYCLES, "simds": N_SIMD, "sclk_mhz_pmc_pass": sclk_mhz,
+                    "frac_pmc_pass": slots / vj["gui_active_per_xcd_per_launch"], "frac": live,
+                    "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x sclk x launch time); sclk = GRBM_GUI_ACTIVE per XCD / launch time "
+                            "in the committed PMC pass, launch time = this run's avg_launch_ms", "source": vj.get("source")}
+            if live > roof["frac"]:
+                roof["bound"] = "valu-issue (see roofline_valu): the kernel sits nearer its VALU issue limit than the HBM roofline"
+        return roof, valu
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,208 +442,150 @@ def main():
     ap.add_argument("--prewarm", type=float, default=0.5,
                     help="seconds of untimed steps before the W warmup steps: the GPU needs ~0.3 s of load to reach its "
                          "sustained clocks (a 5 ms NTT run measures 1.96 M limb-NTT/s, a 0.4 s one 2.40 M)")
+    ap.add_argument("--no-ntt-n16", action="store_true", help="skip the ntt_n16 sub-record of the default (c3) run")
+    ap.add_argument("--relin-group", type=int, default=0, help="FHE_HIP_TUNE_RELIN_GROUP (0 = library default)")
+    ap.add_argument("--e2e", action="store_true",
+                    help="c3 / c5 only: also time the same operations end to end with inputs and results resident on rank 0 only "
+                         "(ShardedEvaluator: chunked scatter / compute / gather), reported beside the compute-only value")
+    ap.add_argument("--e2e-chunk", type=int, default=8, help="ops per rank per scatter/compute/gather chunk in --e2e")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))  # this process never touches the GPU
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d disagrees with WORLD_SIZE=%d of the launcher" % (args.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d has no GPU: %d device(s) visible, --gpus %d" % (rank, torch.cuda.device_count(), args.gpus))
     torch.cuda.set_device(local_rank)
+    sb = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
-    import fhe_amd
-    logN, L, K, Li, dflt_batch = WORKLOADS[args.workload]
-    B = args.batch or dflt_batch
-    N = 1 << logN
-    primes, psi = gen_primes_host(logN, L + K)
-    ctx = fhe_amd.HipContext(logN, L, K, primes, psi, device=local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-
-    # synthetic inputs, resident in HBM: uniform residues below 2^61 (< every prime of the table)
-    gen = torch.Generator(device="cuda").manual_seed(0x5EED0000 + rank)
-
-    def rnd(*shape):
-        return torch.randint(0, 1 << 61, shape, dtype=torch.int64, device="cuda", generator=gen)
-
-    inputs = {"primes": primes, "psi": psi}
-    if args.workload in ("c3", "c5"):
-        c0, c1 = rnd(B, 2, Li, N), rnd(B, 2, Li, N)
-        beta, alpha = rnd(L, L, N), rnd(L, L, N)
-        out = torch.empty((B, 2, Li - 1, N), dtype=torch.int64, device="cuda")
-        ctx.load_mult_key(beta, alpha)
-        step = lambda: ctx.mul_relin_rescale(out, c0, c1, Li, batch=B)  # noqa: E731
-        metric, unit = "ct-mult+relin+rescale/sec at N=2^%d, Li=%d" % (logN, Li), "ops/s"
-    elif args.workload == "c4":
-        ct = rnd(B, 2, Li, N)
-        rkb, rka = rnd(L + K, N), rnd(L + K, N)
-        galois = 3
-        ctx.load_rot_key(galois, rkb, rka)
-        work = ct.clone()
-        step = lambda: ctx.rotate(galois, work, Li, batch=B)  # noqa: E731
-        metric, unit = "rotation-keyswitch/sec at N=2^%d, Li=K=%d" % (logN, Li), "ops/s"
-    elif args.workload in GENERIC:
-        host = lambda t: t.cpu().numpy().view(np.uint64)  # noqa: E731
-        if args.workload in ("rotm", "rotnn"):
-            ct = rnd(B, 2, Li, N)
-            work = ct.clone()
-            galois = 3
-            if args.workload == "rotm":
-                kb, ka = rnd(L, L + 1, N), rnd(L, L + 1, N)
-                ctx.load_mixed_rot_key(galois, kb, ka)
-                step = lambda: ctx.rotate_mixed(galois, work, Li, batch=B)  # noqa: E731
-                metric = "MixedRotKey rotation-keyswitch/sec at N=2^%d, Li=%d" % (logN, Li)
-                inputs["cpu_one"] = lambda o: (lambda i, c=host(ct[:1]), b=host(kb), a=host(ka): o.rotate_mixed(c[0, 0], c[0, 1], galois, b, a))
-            else:
-                kb, ka = rnd(L + K, N), rnd(L + K, N)
-                ctx.load_rot_key(galois, kb, ka)
-                step = lambda: ctx.rotate_non_ntt(galois, work, Li, batch=B)  # noqa: E731
-                metric = "power-basis rotation-keyswitch/sec at N=2^%d, Li=K=%d" % (logN, Li)
-                inputs["cpu_one"] = lambda o: (lambda i, c=host(ct[:1]), b=host(kb), a=host(ka): o.rotate_non_ntt(c[0, 0], c[0, 1], galois, b, a))
-            unit = "ops/s"
-        elif args.workload == "dec":
-            ct, sx = rnd(B, 2, Li, N), rnd(L, N)
-            out = torch.empty((B, Li, N), dtype=torch.int64, device="cuda")
-            step = lambda: ctx.decrypt(out, ct, sx, Li, batch=B)  # noqa: E731
-            metric, unit = "decrypt (bx + sx*ax, INTT)/sec at N=2^%d, Li=%d" % (logN, Li), "ops/s"
-            inputs["cpu_one"] = lambda o: (lambda i, c=host(ct[:1]), s_=host(sx): o.decrypt(c[0, 0], c[0, 1], s_))
-        else:
-            u, e0m, e1 = rnd(B, Li, N), rnd(B, Li, N), rnd(B, Li, N)
-            pkb, pka = rnd(L, N), rnd(L, N)
-            out = torch.empty((B, 2, Li, N), dtype=torch.int64, device="cuda")
-            step = lambda: ctx.encrypt(out, u, e0m, e1, pkb, pka, Li, batch=B)  # noqa: E731
-            metric, unit = "encrypt (NTT, u*pk + e)/sec at N=2^%d, Li=%d" % (logN, Li), "ops/s"
-            inputs["cpu_one"] = lambda o: (lambda i, a_=host(u[:1]), b_=host(e0m[:1]), c_=host(e1[:1]), p_=host(pkb), q_=host(pka):
-                                           o.encrypt_core(a_[0], b_[0], c_[0], p_, q_))
-        inputs["cpu_unit"] = unit
-    else:
-        x = rnd(B, N)
-        idx = np.tile(np.arange(L, dtype=np.uint32), (B + L - 1) // L)[:B]
-        if args.workload == "c2":
-            def step():
-                ctx.ntt_forward(x, idx)
-                ctx.ntt_backward(x, idx)
-            per_step_units = 2 * B
-        else:
-            step = lambda: ctx.ntt_forward(x, idx)  # noqa: E731
-            per_step_units = B
-        metric, unit = "limb-NTTs/sec at N=2^%d" % logN, "limb-NTT/s"
-    units_per_step = B if args.workload in ("c3", "c4", "c5") + GENERIC else per_step_units
+        from fhe_amd.batching import ShardedBatch
+        sb = ShardedBatch(root=0, device=torch.device("cuda", local_rank))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    t_end = time.perf_counter() + max(0.0, args.prewarm)
-    while time.perf_counter() < t_end:  # untimed: clock ramp (see --prewarm)
-        for _ in range(4):
-            step()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ctx.profile_enable(not os.environ.get("FHE_BENCH_NOPROF"))  # development switch: cost of the per-launch events
-    ctx.profile_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = ctx.profile_get()
-    ctx.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
-    value = units_per_step * args.steps * world / elapsed
+    su = Setup(args.workload, args.batch, local_rank, rank, sb, args.relin_group)
+    logN, L, K, Li, N, B = su.logN, su.L, su.K, su.Li, su.N, su.B
+    elapsed, prof = su.timed(args.steps, args.warmup, args.prewarm, barrier)
+    elapsed = max_over_ranks(elapsed)
+    value = su.per_step_units * args.steps * world / elapsed
     alg = algorithmic_bytes(args.workload, N, Li, K)
-
-    # roofline of the dominant kernel: algorithmic bytes per launch / average launch duration, durations from HIP
-    # events recorded on the launch stream inside the timed region (fhe_hip_profile_*).
-    #  - c3 / c5: relin_rows_mac_kernel (row pass of the Li^2 digit NTTs fused with the key MAC): per ciphertext it
-    #    reads 2*Li^2 key limbs + the Li limbs of ct[2] + the 2*Li addend limbs and writes 2*Li limbs.
-    #  - ntt / c2: the forward cols+rows kernel pair = one limb-NTT = 16*N bytes.
-    #  - c4: the two base-conversion kernels, Li (or K) limbs in, K (or Li) limbs out per conversion.
-    roofline = None
-    def kms(name):
-        return prof.get(name, (0, 0.0))
-    if args.workload in ("c3", "c5"):
-        launches, ms = kms("relin_rows_mac")
-        kname = "relin_rows_mac_kernel"
-        alg_total = units_per_step * args.steps * 8 * N * (2 * Li * Li + 5 * Li)
-        # SURVEY 8(d) also asks for the key-amortised figure: the 2*Li^2 key limbs counted once per launch, not per ciphertext
-        alg_amortised = args.steps * 8 * N * (2 * Li * Li + units_per_step * (Li * Li + 5 * Li))
-    elif args.workload in GENERIC:  # the "next" rows: the whole pipeline of the op against its algorithmic bytes
-        launches = args.steps
-        ms = sum(v[1] for v in prof.values())
-        kname = "whole pipeline: " + " + ".join(sorted(prof))
-        alg_total = units_per_step * args.steps * alg
-    elif args.workload == "c4":
-        launches = kms("bconv_modup")[0] + kms("bconv_moddown")[0]
-        ms = kms("bconv_modup")[1] + kms("bconv_moddown")[1]
-        kname = "bconv_kernel (mod-up + 2x mod-down)"
-        alg_total = units_per_step * args.steps * 8 * N * 3 * (Li + K)
-    else:
-        launches = kms("ntt_fwd_cols")[0]
-        ms = kms("ntt_fwd_cols")[1] + kms("ntt_fwd_rows")[1]
-        kname = "ntt_fwd (ntt_cols_kernel + ntt_rows_kernel pair)"
-        alg_total = B * args.steps * 16 * N
-    if launches and ms > 0:
-        achieved = alg_total / (ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if os.path.exists(tpath) and not args.batch:
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "alg_bytes_per_launch": alg_total / launches, "avg_launch_ms": ms / launches, "launches": launches}
-        if args.workload in ("c3", "c5"):
-            roofline["key_amortised"] = {"alg_bytes_per_launch": alg_amortised / launches,
-                                         "achieved": alg_amortised / (ms * 1e-3) / 1e9,
-                                         "frac": alg_amortised / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                         "note": "keys counted once per launch (shared by the batch through L2), column-pass output t1 read once per ciphertext"}
+    roofline, roofline_valu = su.roofline(prof, args.steps)
 
     result = {
-        "metric": metric, "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": su.metric, "value": value, "unit": su.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "%s: N=2^%d Li=%d K=%d, %d units/step/GPU" % (args.workload, logN, Li, K, units_per_step),
+        "config": {"workload": "%s: N=2^%d Li=%d K=%d, %d units/step/GPU" % (args.workload, logN, Li, K, su.per_step_units),
                    "parallelism": "independent ciphertexts sharded over %d GPU(s), no data-path collective" % world},
         "roofline_whole_op": {"alg_bytes_per_unit": alg, "achieved_GBs": value / world * alg / 1e9,
                               "frac_of_hbm_peak": value / world * alg / 1e9 / HBM_PEAK_GBS},
         "kernel_ms": {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in sorted(prof.items())},
+        "kernel_ms_note": "second, untimed pass of the same steps with per-launch HIP events; the timed region runs with them off",
     }
+    if args.workload in MULT:  # "also report the key-amortised figure 8*N*(6Li - 2 + 2Li^2/B) for batch B"
+        am = 8 * N * (6 * Li - 2 + 2 * Li * Li / B)
+        result["roofline_whole_op"]["key_amortised"] = {"alg_bytes_per_unit": am, "achieved_GBs": value / world * am / 1e9,
+                                                        "frac_of_hbm_peak": value / world * am / 1e9 / HBM_PEAK_GBS}
     if roofline:
         result["roofline"] = roofline
+    if roofline_valu:
+        result["roofline_valu"] = roofline_valu
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        if args.workload in GENERIC:
-            pass  # inputs["cpu_one"] was set with the workload
-        elif args.workload in ("c3", "c5"):
+    # ---- multi-rank only: one operation per rank to rank 0 over RCCL, recomputed there ---------------------------------
+    if world > 1 and args.workload in MULT:
+        def recompute(g0, g1, n):
+            o = torch.empty((n, 2, Li - 1, N), dtype=torch.int64, device="cuda")
+            su.ctx.mul_relin_rescale(o, g0.contiguous(), g1.contiguous(), Li, batch=n)
+            return o
+        su.step()
+        torch.cuda.synchronize()
+        ok, seen = verify_over_collective(sb, recompute, su.c0[:1], su.c1[:1], su.out[:1], (2, Li, N), (2, Li - 1, N))
+        if rank == 0:
+            result["rccl_parity"], result["ranks_seen"] = ok, seen
+
+    # ---- end to end: data starts and ends on rank 0 ----------------------------------------------------------
+    if args.e2e and args.workload in MULT:
+        from fhe_amd.batching import ShardedEvaluator
+        ev = ShardedEvaluator(su.ctx)
+        n_items = B * world
+        r0, r1 = (su.rnd(n_items, 2, Li, N), su.rnd(n_items, 2, Li, N)) if rank == 0 else (None, None)
+        run = lambda: ev.mul_relin_rescale(r0, r1, n_items, Li, chunk=args.e2e_chunk)  # noqa: E731
+        got = run()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(max(1, args.steps // 2)):
+            got = run()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        e2e = {"value": n_items * max(1, args.steps // 2) / dt, "unit": su.unit, "ops_per_call": n_items, "chunk_per_rank": args.e2e_chunk,
+               "compute_only_value": value,
+               "note": "inputs and results resident on rank 0's GPU only; chunked star scatter -> compute -> gather (fhe_amd/batching.py)"}
+        if rank == 0:
+            # bytes through the root per op: 2 inputs out, 1 result back, for the (world-1)/world share that leaves the root
+            e2e["root_link_GBs"] = e2e["value"] * (world - 1) / world * 8 * N * (4 * Li + 2 * (Li - 1)) / 1e9
+            check = torch.empty((1, 2, Li - 1, N), dtype=torch.int64, device="cuda")
+            su.ctx.mul_relin_rescale(check, r0[n_items - 1:].contiguous(), r1[n_items - 1:].contiguous(), Li, batch=1)
+            e2e["last_op_matches_local_recompute"] = bool(torch.equal(check[0], got[n_items - 1]))
+            result["e2e"] = e2e
+        del r0, r1, got
+
+    # bounded host-side sample for the CPU baseline, taken before the inputs are released
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    inputs = su.inputs
+    if want_cpu:
+        if args.workload in MULT:
             nb = min(B, 2)
-            inputs.update(c0=c0[:nb].cpu().numpy().view(np.uint64), c1=c1[:nb].cpu().numpy().view(np.uint64),
-                          beta=beta.cpu().numpy().view(np.uint64), alpha=alpha.cpu().numpy().view(np.uint64))
+            inputs.update(c0=su.c0[:nb].cpu().numpy().view(np.uint64), c1=su.c1[:nb].cpu().numpy().view(np.uint64),
+                          beta=su.beta.cpu().numpy().view(np.uint64), alpha=su.alpha.cpu().numpy().view(np.uint64))
         elif args.workload == "c4":
             nb = min(B, 2)
-            inputs.update(ct=ct[:nb].cpu().numpy().view(np.uint64), rkb=rkb.cpu().numpy().view(np.uint64),
-                          rka=rka.cpu().numpy().view(np.uint64), galois=galois)
-        else:
-            inputs.update(x=rnd(min(B, 256), N).cpu().numpy().view(np.uint64), idx=idx)
+            inputs.update(ct=su.ct[:nb].cpu().numpy().view(np.uint64), rkb=su.rkb.cpu().numpy().view(np.uint64),
+                          rka=su.rka.cpu().numpy().view(np.uint64), galois=su.galois)
+        elif args.workload not in GENERIC:
+            inputs.update(x=su.rnd(min(B, 256), N).cpu().numpy().view(np.uint64), idx=su.idx)
+
+    # ---- the other headline figure on the same line: batched forward limb-NTT at N = 2^16 ---------------------------------
+    if args.workload == "c3" and not args.no_ntt_n16 and not args.batch:
+        del su.c0, su.c1, su.out
+        nt = Setup("ntt", 0, local_rank, rank)
+        el, npf = nt.timed(2 * args.steps, args.warmup, args.prewarm, barrier)
+        el = max_over_ranks(el)
+        nroof, nvalu = nt.roofline(npf, 2 * args.steps)
+        result["ntt_n16"] = {"metric": nt.metric, "value": nt.per_step_units * 2 * args.steps * world / el, "unit": nt.unit,
+                             "limbs_per_step_per_gpu": nt.B, "steps": 2 * args.steps, "ms_per_step": el / (2 * args.steps) * 1e3,
+                             "roofline": nroof, "roofline_valu": nvalu}
+        nt.ctx.close()
+
+    if want_cpu:
         result["cpu_baseline"] = cpu_baseline(args.workload, logN, L, K, Li, inputs, args.cpu_budget)
 
     if rank == 0:
         print(json.dumps(result))
-    ctx.close()
+    su.ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -8,7 +8,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -74,6 +77,11 @@ struct fhe_hip_ctx {
   size_t ws_bytes[6] = {0, 0, 0, 0, 0, 0};
   // entry points that allocate nothing carve their workspaces out of this device's copy of the static scratch array
   // instead (fixed_ws set for the duration of such a call; fixed_used = bytes carved so far)
+  // fhe_hip_batch_run: copy streams, hand-over events and three device staging slots {in0, in1, out / in-place}
+  hipStream_t br_up[2] = {nullptr, nullptr}, br_down[2] = {nullptr, nullptr};   // two copy lanes per direction
+  hipEvent_t br_ev_up[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}}, br_ev_done[3] = {nullptr, nullptr, nullptr};
+  void *br_buf[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  size_t br_bytes[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   unsigned char *scratch = nullptr;
   bool fixed_ws = false; size_t fixed_used = 0;
   uint32_t relin_group = 0;  // output limbs per relinearisation pass (0 = all Li at once): fhe_hip_set_tuning
@@ -770,6 +778,15 @@ void fhe_hip_ctx_destroy(fhe_hip_ctx *c) {
   for (void *p : c->ws) if (p) hipFree(p);
   for (void *p : c->stage) if (p) hipFree(p);
   if (c->d_idx) hipFree(c->d_idx);
+  for (int k = 0; k < 3; ++k) {
+    for (int j = 0; j < 3; ++j) if (c->br_buf[k][j]) hipFree(c->br_buf[k][j]);
+    for (int l = 0; l < 2; ++l) if (c->br_ev_up[l][k]) hipEventDestroy(c->br_ev_up[l][k]);
+    if (c->br_ev_done[k]) hipEventDestroy(c->br_ev_done[k]);
+  }
+  for (int l = 0; l < 2; ++l) {
+    if (c->br_up[l]) hipStreamDestroy(c->br_up[l]);
+    if (c->br_down[l]) hipStreamDestroy(c->br_down[l]);
+  }
   delete c;
 }
 
@@ -1100,41 +1117,158 @@ int fhe_hip_rotate_non_ntt(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32
   return rotate_api(c, galois, ct, Li, batch, mem_kind, true);
 }
 
-// Single-process multi-GPU mode: contiguous split of the batch over the contexts, one host thread per context, each slice
-// in chunks through the ordinary host-pointer entry points (which stage through that context's device buffers).
+// Single-process multi-GPU mode: contiguous split of the batch over the contexts (the rule of fhe_amd/batching.py:shard_bounds:
+// the first batch % n_ctx contexts take one operation more).  Every context runs its slice as a three-stage pipeline over
+// chunks of at most 32 operations and three device staging slots: an uploader thread (host -> device on a stream of its own),
+// the slice's own thread (the operation, enqueued on the context's stream on device pointers) and a downloader thread (device
+// -> host on a third stream).  The stages hand chunks over through HIP events (device side) and a progress counter (host
+// side), so the upload of chunk k+1 and the download of chunk k-1 run under the computation of chunk k, and, the host link
+// being full duplex, under each other: with pageable caller memory a copy blocks only the thread that issued it.
+namespace {
+
+constexpr size_t BR_CHUNK = 32;
+constexpr int BR_SLOTS = 3;
+constexpr int BR_LANES = 2;   // copy threads (and streams) per direction: one thread's pageable copy does not fill the host link
+
+struct BatchPipe {
+  std::mutex mu; std::condition_variable cv;
+  size_t up_done[BR_LANES] = {0, 0}, comp_done = 0, down_done[BR_LANES] = {0, 0};   // chunks that have left each stage / lane
+  bool failed = false;
+  int rc = FHE_HIP_OK; std::string err;
+  void fail(int code, const std::string &msg) {
+    std::lock_guard<std::mutex> l(mu);
+    if (!failed) { failed = true; rc = code; err = msg; }
+    cv.notify_all();
+  }
+  // wait until every given counter exceeds k (or the slice has failed): false = stop
+  bool wait_for(const size_t *counters, int n, size_t k) {
+    std::unique_lock<std::mutex> l(mu);
+    cv.wait(l, [&] {
+      if (failed) return true;
+      for (int i = 0; i < n; ++i) if (counters[i] <= k) return false;
+      return true;
+    });
+    return !failed;
+  }
+  void advance(size_t &counter) {
+    { std::lock_guard<std::mutex> l(mu); ++counter; }
+    cv.notify_all();
+  }
+};
+
+int batch_ensure(fhe_hip_ctx *c, size_t in_bytes, size_t out_bytes, bool two_inputs) {
+  if (!c->br_up[0]) {
+    for (int l = 0; l < BR_LANES; ++l) {
+      HIPCHK(c, hipStreamCreateWithFlags(&c->br_up[l], hipStreamNonBlocking));
+      HIPCHK(c, hipStreamCreateWithFlags(&c->br_down[l], hipStreamNonBlocking));
+      for (int k = 0; k < BR_SLOTS; ++k) HIPCHK(c, hipEventCreateWithFlags(&c->br_ev_up[l][k], hipEventDisableTiming));
+    }
+    for (int k = 0; k < BR_SLOTS; ++k) HIPCHK(c, hipEventCreateWithFlags(&c->br_ev_done[k], hipEventDisableTiming));
+  }
+  for (int k = 0; k < BR_SLOTS; ++k) {
+    const size_t want[3] = {two_inputs ? in_bytes : 0, two_inputs ? in_bytes : 0, out_bytes};
+    for (int j = 0; j < 3; ++j) {
+      if (c->br_bytes[k][j] >= want[j]) continue;
+      if (c->br_buf[k][j]) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->br_buf[k][j])); c->br_buf[k][j] = nullptr; c->br_bytes[k][j] = 0; }
+      HIPCHK(c, hipMalloc(&c->br_buf[k][j], want[j]));
+      c->br_bytes[k][j] = want[j];
+    }
+  }
+  return FHE_HIP_OK;
+}
+
+}  // namespace
+
 int fhe_hip_batch_run(fhe_hip_ctx *const *ctxs, uint32_t n_ctx, int op, uint64_t *out, const uint64_t *in0, const uint64_t *in1,
                       uint64_t galois, uint32_t Li, size_t batch, int mem_kind) {
   try {
   if (!ctxs || n_ctx == 0) return FHE_HIP_ERR_ARG;
-  for (u32 g = 0; g < n_ctx; ++g) if (!ctxs[g]) return FHE_HIP_ERR_ARG;
+  for (u32 g = 0; g < n_ctx; ++g) { if (!ctxs[g]) return FHE_HIP_ERR_ARG; ctxs[g]->err.clear(); }
   fhe_hip_ctx *c0 = ctxs[0];
   if (mem_kind != FHE_HIP_MEM_HOST) FAIL(c0, FHE_HIP_ERR_ARG, "fhe_hip_batch_run takes host pointers only");
   if (op != FHE_HIP_OP_MUL_RELIN_RESCALE && op != FHE_HIP_OP_ROTATE && op != FHE_HIP_OP_ROTATE_MIXED && op != FHE_HIP_OP_ROTATE_NON_NTT) FAIL(c0, FHE_HIP_ERR_ARG, "unknown op");
-  if (!out || (op == FHE_HIP_OP_MUL_RELIN_RESCALE && (!in0 || !in1))) FAIL(c0, FHE_HIP_ERR_ARG, "null argument");
+  const bool mul = op == FHE_HIP_OP_MUL_RELIN_RESCALE;
+  if (!out || (mul && (!in0 || !in1))) FAIL(c0, FHE_HIP_ERR_ARG, "null argument");
   for (u32 g = 1; g < n_ctx; ++g)
     if (ctxs[g]->logN != c0->logN || ctxs[g]->L != c0->L || ctxs[g]->K != c0->K) FAIL(c0, FHE_HIP_ERR_ARG, "contexts of one set must share (logN, L, K)");
   for (u32 g = 0; g < n_ctx; ++g)
     for (u32 h = g + 1; h < n_ctx; ++h)
       if (ctxs[g] == ctxs[h]) FAIL(c0, FHE_HIP_ERR_ARG, "a context may appear once in a set (a context is not thread-safe)");
-  TRY(check_li(c0, Li, 2));
+  TRY(check_li(c0, Li, op == FHE_HIP_OP_ROTATE_MIXED ? 1 : 2));  // the per-op minimum of the single-context entry points
   if (batch == 0) return FHE_HIP_OK;
   const u64 N = c0->N;
-  const size_t in_ct = (size_t)2 * Li * N, out_ct = (size_t)2 * (op == FHE_HIP_OP_MUL_RELIN_RESCALE ? Li - 1 : Li) * N;
-  constexpr size_t CHUNK = 32;
+  const size_t in_ct = (size_t)2 * Li * N, out_ct = (size_t)2 * (mul ? Li - 1 : Li) * N;
   std::vector<int> rc(n_ctx, FHE_HIP_OK);
+
   auto slice = [&](u32 g) {
-    const size_t lo = batch * g / n_ctx, hi = batch * (g + 1) / n_ctx;
-    for (size_t at = lo; at < hi && rc[g] == FHE_HIP_OK; at += CHUNK) {
-      const size_t n = std::min(CHUNK, hi - at);
-      if (op == FHE_HIP_OP_MUL_RELIN_RESCALE)
-        rc[g] = fhe_hip_mul_relin_rescale(ctxs[g], out + at * out_ct, in0 + at * in_ct, in1 + at * in_ct, Li, n, FHE_HIP_MEM_HOST);
-      else if (op == FHE_HIP_OP_ROTATE)
-        rc[g] = fhe_hip_rotate(ctxs[g], galois, out + at * out_ct, Li, n, FHE_HIP_MEM_HOST);
-      else if (op == FHE_HIP_OP_ROTATE_MIXED)
-        rc[g] = fhe_hip_rotate_mixed(ctxs[g], galois, out + at * out_ct, Li, n, FHE_HIP_MEM_HOST);
-      else
-        rc[g] = fhe_hip_rotate_non_ntt(ctxs[g], galois, out + at * out_ct, Li, n, FHE_HIP_MEM_HOST);
+    fhe_hip_ctx *c = ctxs[g];
+    const size_t base = batch / n_ctx, rem = batch % n_ctx;
+    const size_t lo = g * base + std::min<size_t>(g, rem), hi = lo + base + (g < rem ? 1 : 0);
+    if (hi == lo) return;
+    if ((rc[g] = check_ctx(c)) != FHE_HIP_OK) return;
+    const size_t per_chunk = std::min(BR_CHUNK, hi - lo), nchunks = (hi - lo + BR_CHUNK - 1) / BR_CHUNK;
+    if ((rc[g] = batch_ensure(c, per_chunk * in_ct * 8, per_chunk * out_ct * 8, mul)) != FHE_HIP_OK) return;
+    BatchPipe pipe;
+    auto chunk_n = [&](size_t k) { return std::min(BR_CHUNK, hi - lo - k * BR_CHUNK); };
+    auto hip_fail = [&](const char *what, hipError_t e) { pipe.fail(FHE_HIP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
+    // lane 0 / 1 of a direction move the first / second half of a chunk's words (two inputs: in0 / in1)
+    auto uploader = [&](int lane) {
+      hipError_t e = hipSetDevice(c->device);
+      if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+      for (size_t k = 0; k < nchunks; ++k) {
+        if (k >= BR_SLOTS && !pipe.wait_for(pipe.down_done, BR_LANES, k - BR_SLOTS)) return;  // the slot's previous chunk has been downloaded
+        const int s = (int)(k % BR_SLOTS);
+        const size_t at = lo + k * BR_CHUNK, n = chunk_n(k);
+        if (mul) {
+          const uint64_t *src = (lane == 0 ? in0 : in1) + at * in_ct;
+          if ((e = hipMemcpyAsync(c->br_buf[s][lane], src, n * in_ct * 8, hipMemcpyHostToDevice, c->br_up[lane])) != hipSuccess) return hip_fail("hipMemcpyAsync (upload)", e);
+        } else {
+          const size_t words = n * out_ct, half = words / 2, w0 = lane == 0 ? 0 : half, wn = lane == 0 ? half : words - half;
+          if ((e = hipMemcpyAsync((uint64_t *)c->br_buf[s][2] + w0, out + at * out_ct + w0, wn * 8, hipMemcpyHostToDevice, c->br_up[lane])) != hipSuccess) return hip_fail("hipMemcpyAsync (upload)", e);
+        }
+        if ((e = hipEventRecord(c->br_ev_up[lane][s], c->br_up[lane])) != hipSuccess) return hip_fail("hipEventRecord", e);
+        pipe.advance(pipe.up_done[lane]);
+      }
+    };
+    auto downloader = [&](int lane) {
+      hipError_t e = hipSetDevice(c->device);
+      if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+      for (size_t k = 0; k < nchunks; ++k) {
+        if (!pipe.wait_for(&pipe.comp_done, 1, k)) return;
+        const int s = (int)(k % BR_SLOTS);
+        const size_t at = lo + k * BR_CHUNK, n = chunk_n(k);
+        const size_t words = n * out_ct, half = words / 2, w0 = lane == 0 ? 0 : half, wn = lane == 0 ? half : words - half;
+        if ((e = hipStreamWaitEvent(c->br_down[lane], c->br_ev_done[s], 0)) != hipSuccess) return hip_fail("hipStreamWaitEvent", e);
+        if ((e = hipMemcpyAsync(out + at * out_ct + w0, (const uint64_t *)c->br_buf[s][2] + w0, wn * 8, hipMemcpyDeviceToHost, c->br_down[lane])) != hipSuccess) return hip_fail("hipMemcpyAsync (download)", e);
+        if ((e = hipStreamSynchronize(c->br_down[lane])) != hipSuccess) return hip_fail("hipStreamSynchronize", e);
+        pipe.advance(pipe.down_done[lane]);
+      }
+    };
+    std::thread copy_t[2 * BR_LANES];
+    bool all_started = true;
+    try { for (int l = 0; l < BR_LANES; ++l) { copy_t[l] = std::thread(uploader, l); copy_t[BR_LANES + l] = std::thread(downloader, l); } }
+    catch (...) { all_started = false; pipe.fail(FHE_HIP_ERR_HIP, "cannot start the copy threads of fhe_hip_batch_run"); }
+    for (size_t k = 0; k < nchunks && all_started; ++k) {
+      if (!pipe.wait_for(pipe.up_done, BR_LANES, k)) break;
+      const int s = (int)(k % BR_SLOTS);
+      const size_t n = chunk_n(k);
+      hipError_t e = hipSuccess;
+      for (int l = 0; l < BR_LANES && e == hipSuccess; ++l) e = hipStreamWaitEvent(c->stream, c->br_ev_up[l][s], 0);
+      if (e != hipSuccess) { hip_fail("hipStreamWaitEvent", e); break; }
+      uint64_t *d = (uint64_t *)c->br_buf[s][2];
+      int r;
+      if (mul) r = fhe_hip_mul_relin_rescale(c, d, (const uint64_t *)c->br_buf[s][0], (const uint64_t *)c->br_buf[s][1], Li, n, FHE_HIP_MEM_DEVICE);
+      else if (op == FHE_HIP_OP_ROTATE) r = fhe_hip_rotate(c, galois, d, Li, n, FHE_HIP_MEM_DEVICE);
+      else if (op == FHE_HIP_OP_ROTATE_MIXED) r = fhe_hip_rotate_mixed(c, galois, d, Li, n, FHE_HIP_MEM_DEVICE);
+      else r = fhe_hip_rotate_non_ntt(c, galois, d, Li, n, FHE_HIP_MEM_DEVICE);
+      if (r != FHE_HIP_OK) { pipe.fail(r, c->err); break; }
+      if ((e = hipEventRecord(c->br_ev_done[s], c->stream)) != hipSuccess) { hip_fail("hipEventRecord", e); break; }
+      pipe.advance(pipe.comp_done);
     }
+    for (auto &t : copy_t) if (t.joinable()) t.join();
+    for (int l = 0; l < BR_LANES; ++l) { hipStreamSynchronize(c->br_up[l]); hipStreamSynchronize(c->br_down[l]); }
+    hipStreamSynchronize(c->stream);  // nothing of this call outlives it
+    if (pipe.failed) { rc[g] = pipe.rc; c->err = pipe.err; }
   };
   std::vector<std::thread> workers;
   u32 started = 1;

@@ -130,17 +130,19 @@ int fhe_hip_decrypt(fhe_hip_ctx *ctx, uint64_t *out, const uint64_t *ct, const u
 int fhe_hip_encrypt(fhe_hip_ctx *ctx, uint64_t *ct, const uint64_t *u, const uint64_t *e0m, const uint64_t *e1,
                     const uint64_t *pk_b, const uint64_t *pk_a, uint32_t Li, size_t batch, int mem_kind);
 
-/* Single-process multi-GPU mode ("one ctx + stream set per device", batch index split contiguously:
- * context g gets ops [g*B/G, (g+1)*B/G)).  No counterpart in the reference, which is single-threaded on one CPU; the
- * sharding rule is the one of fhe_amd/batching.py (one process per GPU).  ctxs = n_ctx contexts, normally one per GPU,
- * created with the same (logN, L, K, primes, psi) and each already holding the keys the op needs; every context runs its
- * slice on a host thread of its own, in chunks of at most 32 ops staged through that context's device buffers (host
- * pointers only: mem_kind must be FHE_HIP_MEM_HOST; device-resident callers drive the per-context entry points from their
- * own threads).  Independent ciphertexts, no collective.  Returns the first non-zero status of any slice
- * (fhe_hip_last_error(ctxs[g]) has the message).
+/* Single-process multi-GPU mode ("one ctx + stream set per device", batch index split contiguously).  No
+ * counterpart in the reference, which is single-threaded on one CPU; the split is the rule of fhe_amd/batching.py
+ * (shard_bounds: context g gets batch / n_ctx operations, the first batch % n_ctx contexts one more).  ctxs = n_ctx contexts,
+ * normally one per GPU, created with the same (logN, L, K, primes, psi) and each already holding the keys the op needs.
+ * Every context runs its slice on a host thread of its own as a pipeline over chunks of at most 32 operations and three
+ * device staging slots: upload of chunk k+1 and download of chunk k-1 (two more threads and streams per context) run under
+ * the computation of chunk k.  Host pointers only (mem_kind must be FHE_HIP_MEM_HOST; pageable or pinned: pinned memory
+ * doubles the copy rate); device-resident callers drive the per-context entry points from their own threads.  Independent
+ * ciphertexts, no collective.  Returns the first non-zero status of any slice; fhe_hip_last_error(ctxs[g]) is empty for the
+ * contexts whose slice succeeded and carries the message for the ones that failed.
  *   FHE_HIP_OP_MUL_RELIN_RESCALE: out = [batch][2][Li-1][N], in0, in1 = [batch][2][Li][N]   (fhe_hip_mul_relin_rescale)
  *   FHE_HIP_OP_ROTATE / _ROTATE_MIXED / _ROTATE_NON_NTT: out = [batch][2][Li][N] in place, in0 = in1 = NULL, galois
- *                                 (fhe_hip_rotate, fhe_hip_rotate_mixed, fhe_hip_rotate_non_ntt) */
+ *                                 (fhe_hip_rotate, fhe_hip_rotate_mixed, fhe_hip_rotate_non_ntt; Li >= 1 for _ROTATE_MIXED) */
 #define FHE_HIP_OP_MUL_RELIN_RESCALE 1
 #define FHE_HIP_OP_ROTATE 2
 #define FHE_HIP_OP_ROTATE_MIXED 3

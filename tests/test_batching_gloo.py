@@ -78,3 +78,49 @@ def test_sharded_output_equals_single_rank_output(tmp_path, n_items, chunk):
     result = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(2, _free_port(), n_items, chunk, result), nprocs=2, join=True)
     assert open(result).read() == "ok"
+
+
+def _verify_worker(rank, world, port, corrupt, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from oracle import oracle as orc
+    logN, L, K, Li = 10, 3, 1, 3
+    o = orc.Oracle(logN, L, K)
+    N = o.N
+    sx, _ = o.keygen_sk(seed=5)
+    beta, alpha = o.keygen_mult(sx, seed=6)
+
+    def compute(c0, c1, n):  # stands in for the rank's GPU: same keys on every rank
+        out = np.zeros((n, 2, Li - 1, N), np.uint64)
+        a, b = c0.numpy().view(np.uint64), c1.numpy().view(np.uint64)
+        for k in range(n):
+            out[k, 0], out[k, 1] = o.mul_relin_rescale(np.ascontiguousarray(a[k, 0]), np.ascontiguousarray(a[k, 1]),
+                                                       np.ascontiguousarray(b[k, 0]), np.ascontiguousarray(b[k, 1]), beta, alpha)
+        return torch.from_numpy(out.view(np.int64))
+
+    rng = np.random.default_rng(100 + rank)  # every rank has its own operation, as in bench.py
+    mk = lambda: torch.from_numpy(np.stack([np.stack([rng.integers(0, int(o.primes[i]), N, dtype=np.uint64) for i in range(Li)])  # noqa: E731
+                                            for _ in range(2)])[None].view(np.int64))
+    c0, c1 = mk(), mk()
+    out = compute(c0, c1, 1)
+    if corrupt and rank == 1:
+        out[0, 1, 0, 7] ^= 1  # one flipped bit in what rank 1 "computed"
+    ok, seen = bench.verify_over_collective(ShardedBatch(root=0), compute, c0, c1, out, (2, Li, N), (2, Li - 1, N))
+    if rank == 0:
+        open(result_path, "w").write("%s %s" % (ok, seen))
+    else:
+        assert ok is None and seen is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("corrupt,expect", [(False, "True 2"), (True, "False 1")])
+def test_post_run_parity_check_over_the_collective(tmp_path, corrupt, expect):
+    """bench.py --gpus N: one operation per rank travels to rank 0 and is recomputed there (`rccl_parity`, `ranks_seen`)."""
+    result = str(tmp_path / "verify.txt")
+    mp.spawn(_verify_worker, args=(2, _free_port(), corrupt, result), nprocs=2, join=True)
+    assert open(result).read() == expect
