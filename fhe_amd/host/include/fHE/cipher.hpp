@@ -1,29 +1,27 @@
-// fHE/cipher.hpp — same value type as reference include/fHE/cipher.hpp:5-50.
+// fHE/cipher.hpp — the ciphertext value type, same members and meaning as the reference's (include/fHE/cipher.hpp):
+// bx / ax are the two halves, mul_aux the degree-2 part a multiplication leaves until relinearisation, scale the CKKS scale.
 #pragma once
 #include "fHE/context.hpp"
 #include <memory>
 namespace fHE {
 struct Cipher {
+  context::poly_t bx, ax;
+  std::shared_ptr<context::poly_t> mul_aux;  // shared between copies, like every other part of a copied ciphertext's history
+
+  // a fresh ciphertext over the first `limbs` normal primes
+  explicit Cipher(size_t limbs = context::nr_ctxt_moduli) : bx(limbs), ax(limbs) { assert(limbs < yell::params::kMaxNbModuli); }
+  // value semantics: memberwise copy, move and assignment are exactly what is wanted
+  Cipher(Cipher const &) = default;
+  Cipher(Cipher &&) = default;
+  Cipher &operator=(Cipher const &) = default;
+  Cipher &operator=(Cipher &&) = default;
+
+  size_t moduli_count() const { return bx.moduli_count(); }
+  bool canonical() const { return !mul_aux; }  // degree 1: nothing waits for relinearisation
+  double scale() const { return scale_; }
+  void scale(double s) { assert(s > 0.); scale_ = s; }
+
  private:
   double scale_ = 1.;
-
- public:
-  context::poly_t bx;
-  context::poly_t ax;
-  std::shared_ptr<context::poly_t> mul_aux = nullptr;
-
-  explicit Cipher(size_t L = context::nr_ctxt_moduli) : bx(L), ax(L) { assert(L < yell::params::kMaxNbModuli); }
-  Cipher(const Cipher &oth) : scale_(oth.scale_), bx(oth.bx), ax(oth.ax), mul_aux(oth.mul_aux) {}
-  Cipher(Cipher &&oth) : scale_(oth.scale_), bx(std::move(oth.bx)), ax(std::move(oth.ax)), mul_aux(std::move(oth.mul_aux)) {}
-  ~Cipher() {}
-  Cipher &operator=(Cipher oth) {
-    std::swap(bx, oth.bx); std::swap(ax, oth.ax); std::swap(mul_aux, oth.mul_aux);
-    scale_ = oth.scale_;
-    return *this;
-  }
-  bool canonical() const { return mul_aux == nullptr; }
-  double scale() const { return scale_; }
-  size_t moduli_count() const { return bx.moduli_count(); }
-  void scale(double s) { assert(s > 0.); scale_ = s; }
 };
 }  // namespace fHE

@@ -65,6 +65,7 @@ class Context {
   Context(Context const &) = delete;
   Context &operator=(Context const &) = delete;
   ~Context() {
+    yell::runtime::get().loaded.erase(ctx_);
     if (yell::runtime::get().ctx == ctx_) yell::runtime::get().ctx = nullptr;
     fhe_hip_ctx_destroy(ctx_);
   }

@@ -1,48 +1,45 @@
-// fHE/decryptor.hpp — polynomial-level decrypt of reference src/decryptor.cpp:11-38 (the integer
-// "decrypted-plaintext" parity probe).  The Encoder overloads (:40-78) decode on the host (fHE/encoder.hpp).
+// fHE/decryptor.hpp — Decryptor with the reference's public shape (include/fHE/decryptor.hpp:11-23).  The polynomial-level
+// decrypt (src/decryptor.cpp:11-38: bx + sx*ax per limb, then the inverse NTT) is ONE device call, fhe_hip_decrypt; it is
+// the integer "decrypted-plaintext" parity probe.  The value overloads decode on the host (fHE/encoder.hpp).
 #pragma once
 #include "fHE/cipher.hpp"
 #include "fHE/encoder.hpp"
 #include "fHE/keys.hpp"
-#include "fHE/yell.hpp"
+#include <complex>
 namespace fHE {
 struct Decryptor {
   explicit Decryptor(std::shared_ptr<Encoder> encoder = nullptr) : encoder(encoder) {}
   ~Decryptor() {}
-  bool decrypt(context::poly_t *rop, Cipher const &ctx, SK const &sk) const {
-    using T = yell::params::value_type; using gT = yell::params::gt_value_type;
-    const size_t degree = context::degree, nmoduli = ctx.moduli_count();
-    if (nmoduli > sk.sx.moduli_count()) throw std::runtime_error("Impossible.");
-    if (!ctx.canonical()) throw std::runtime_error("Call relinear before decryption.");
+
+  // throws std::runtime_error like the reference when the secret key has fewer limbs than the ciphertext or the
+  // ciphertext still carries its degree-2 part; false on a null result pointer
+  bool decrypt(context::poly_t *rop, Cipher const &ct, SK const &sk) const {
+    const size_t Li = ct.moduli_count(), n = context::degree;
+    if (Li > sk.sx.moduli_count()) throw std::runtime_error("decrypt: the ciphertext has more limbs than the secret key");
+    if (!ct.canonical()) throw std::runtime_error("decrypt: relinearize the ciphertext first");
     if (!rop) return false;
-    rop->resize_moduli_count(nmoduli);
-    for (size_t cm = 0; cm < nmoduli; ++cm) {
-      std::vector<gT> lazy(degree);
-      std::transform(ctx.bx.cptr_at(cm), ctx.bx.cptr_end(cm), lazy.data(), [](T v) { return (gT)v; });
-      lazy_muladd(lazy.data(), sk.sx.cptr_at(cm), ctx.ax.cptr_at(cm), degree);  //! m = bx + sx * ax
-      auto dst = rop->ptr_at(cm);
-      for (auto &v : lazy) { yell::ops::barret_reduction(&v, cm); *dst++ = (T)v; }
-    }
-    rop->backward();
-    return true;
+    rop->resize_moduli_count(Li);
+    if (Li == 0) return true;
+    std::vector<detail::word> halves(2 * Li * n);
+    std::copy(ct.bx.cptr_at(0), ct.bx.cptr_at(0) + Li * n, halves.begin());
+    std::copy(ct.ax.cptr_at(0), ct.ax.cptr_at(0) + Li * n, halves.begin() + Li * n);
+    return fhe_hip_decrypt(yell::runtime::get().ctx, rop->ptr_at(0), halves.data(), sk.sx.cptr_at(0), (uint32_t)Li, 1, FHE_HIP_MEM_HOST) == FHE_HIP_OK;
   }
-  bool decrypt(std::vector<std::complex<double>> *rop, Cipher const &ctx, SK const &sk) const { return decrypt_values(rop, ctx, sk); }  // :40-50
-  bool decrypt(std::vector<double> *rop, Cipher const &ctx, SK const &sk) const { return decrypt_values(rop, ctx, sk); }  // :52-61
-  bool decrypt(double *rop, Cipher const &ctx, SK const &sk) const {  // :63-77
-    if (!rop) return false;
-    std::vector<double> val;
-    if (!decrypt(&val, ctx, sk)) return false;
-    *rop = val[0];
+  bool decrypt(std::vector<std::complex<double>> *rop, Cipher const &ct, SK const &sk) const { return decrypt_then_decode(rop, ct, sk); }
+  bool decrypt(std::vector<double> *rop, Cipher const &ct, SK const &sk) const { return decrypt_then_decode(rop, ct, sk); }
+  bool decrypt(double *rop, Cipher const &ct, SK const &sk) const {
+    std::vector<double> slots;
+    if (!rop || !decrypt(&slots, ct, sk) || slots.empty()) return false;
+    *rop = slots.front();
     return true;
   }
 
  private:
-  template <class V>
-  bool decrypt_values(V *rop, Cipher const &ctx, SK const &sk) const {
+  template <class Values> bool decrypt_then_decode(Values *rop, Cipher const &ct, SK const &sk) const {
     if (!rop || !encoder) return false;
-    context::poly_t plain(ctx.moduli_count());
-    if (!decrypt(&plain, ctx, sk)) return false;
-    encoder->decode(rop, plain, ctx.scale());
+    context::poly_t plain(ct.moduli_count());
+    if (!decrypt(&plain, ct, sk)) return false;
+    encoder->decode(rop, plain, ct.scale());
     return true;
   }
   std::shared_ptr<Encoder> encoder;

@@ -1,4 +1,4 @@
-// fHE/encoder.hpp — host mirror of reference include/fHE/encoder.hpp:6-46 / src/encoder.cpp:5-200:
+// fHE/encoder.hpp — host Encoder with the reference's public shape (include/fHE/encoder.hpp:6-46):
 // CKKS canonical-embedding encoder.  Floating point, host only; it exists so that Evaluator::replicate (which encodes a
 // slot mask) and full pipelines can run on the mirror.  The reference goes through GMP (mpz_set_d / mpz_mod_ui /
 // poly2mpz); here the same integers are formed with 128-bit and small multi-word arithmetic (no GMP dependency).
@@ -16,53 +16,49 @@ struct Encoder {
   const size_t degree = context::degree;
   const size_t nr_slots = degree >> 1u;
   const size_t logn = yell::runtime::get().logn;
-  const size_t generator = 3;
-  std::vector<uint32_t> matrix_reps_index_map_;
-  std::vector<cplx> roots_, inv_roots_;
+  // Canonical embedding.  With zeta = exp(2 pi i / 2N), a real polynomial m is fixed by its values at the N odd powers
+  // zeta^(2k+1), k = 0..N-1, and those values come in conjugate pairs.  Slot j is the value at zeta^(3^j) (3 generates the
+  // odd residues mod 2N up to sign), its conjugate sits at zeta^(-3^j):
+  //     point_[j] = (3^j mod 2N - 1) / 2,   point_[N/2 + j] = (2N - 3^j mod 2N - 1) / 2        (the k of each of them)
+  // Evaluating at all odd powers is a twist followed by an ordinary cyclic DFT of size N:
+  //     m(zeta^(2k+1)) = sum_d (m_d zeta^d) omega^(k d),  omega = zeta^2 = exp(2 pi i / N).
+  // (The reference reaches the same numbers with a negacyclic butterfly network over bit-reversed roots,
+  // src/encoder.cpp:6-100; values agree to floating-point rounding, which the tests bound.)
+  std::vector<uint32_t> point_;
+  std::vector<cplx> omega_;  // omega^k, k < N/2
+  std::vector<cplx> twist_;  // zeta^d, d < N
 
-  void FFT_inplace(std::vector<cplx> &res) const {  // encoder.cpp:38-58
-    size_t tt = degree;
-    for (size_t i = 0; i < logn; i++) {
-      const size_t mm = size_t(1) << i;
-      tt >>= 1;
-      for (size_t j = 0; j < mm; j++) {
-        const size_t j1 = 2 * j * tt;
-        const cplx s = roots_[mm + j];
-        for (size_t k = j1; k < j1 + tt; k++) {
-          const cplx u = res[k], v = res[k + tt] * s;
-          res[k] = u + v;
-          res[k + tt] = u - v;
-        }
-      }
-    }
-  }
-  void iFFT_inplace(std::vector<cplx> &res) const {  // encoder.cpp:60-83 (no 1/N: folded into delta by encode)
-    size_t tt = 1;
-    for (size_t i = 0; i < logn; i++) {
-      const size_t h = (size_t(1) << (logn - i)) / 2;
-      size_t k_start = 0;
-      for (size_t j = 0; j < h; j++) {
-        const cplx s = inv_roots_[h + j];
-        for (size_t k = k_start; k < k_start + tt; k++) {
-          const cplx u = res[k], v = res[k + tt];
-          res[k] = u + v;
-          res[k + tt] = (u - v) * s;
-        }
-        k_start += 2 * tt;
-      }
-      tt *= 2;
-    }
-  }
-  std::vector<cplx> apply_ifft(std::vector<cplx> const &values) const {  // encoder.cpp:84-100
-    const size_t n = std::min(values.size(), nr_slots);
-    if (n != values.size()) std::cerr << "WARN: Too many values to encode." << "Just handle the first " << nr_slots << " values.\n";
-    std::vector<cplx> conj_values(degree, 0.);
+  // in-place cyclic DFT of size N, x_k <- sum_d x_d omega^(sign k d): bit-reversal permutation, then log2 N butterfly stages
+  void cyclic_dft(std::vector<cplx> &x, bool conjugate) const {
+    const size_t n = degree;
     for (size_t i = 0; i < n; ++i) {
-      conj_values[matrix_reps_index_map_[i]] = values[i];
-      conj_values[matrix_reps_index_map_[i + nr_slots]] = std::conj(values[i]);
+      const size_t r = (size_t)yell::math::reverse_bits(i, logn);
+      if (i < r) std::swap(x[i], x[r]);
     }
-    iFFT_inplace(conj_values);
-    return conj_values;
+    for (size_t len = 2; len <= n; len <<= 1) {
+      const size_t half = len >> 1, stride = n / len;
+      for (size_t start = 0; start < n; start += len) {
+        for (size_t k = 0; k < half; ++k) {
+          const cplx w = conjugate ? std::conj(omega_[k * stride]) : omega_[k * stride];
+          const cplx odd = x[start + half + k] * w, even = x[start + k];
+          x[start + k] = even + odd;
+          x[start + half + k] = even - odd;
+        }
+      }
+    }
+  }
+  // slot values -> N * (coefficients of the real polynomial that takes them); the 1/N is folded into encode's scale
+  std::vector<cplx> coefficients_times_n(std::vector<cplx> const &values) const {
+    const size_t used = std::min(values.size(), nr_slots);
+    if (used != values.size()) std::cerr << "WARN: Too many values to encode." << "Just handle the first " << nr_slots << " values.\n";
+    std::vector<cplx> at_points(degree, 0.);
+    for (size_t j = 0; j < used; ++j) {
+      at_points[point_[j]] = values[j];
+      at_points[point_[nr_slots + j]] = std::conj(values[j]);
+    }
+    cyclic_dft(at_points, true);  // sum_k E_k omega^(-k d)
+    for (size_t d = 0; d < degree; ++d) at_points[d] *= std::conj(twist_[d]);
+    return at_points;
   }
 
   // trunc(x) mod p in [0,p), what mpz_set_d + mpz_mod_ui give (encoder.cpp:135-136)
@@ -112,27 +108,23 @@ struct Encoder {
   }
 
  public:
-  explicit Encoder() : matrix_reps_index_map_(degree), roots_(degree), inv_roots_(degree) {  // encoder.cpp:6-34
-    const size_t m = degree << 1u;
-    uint64_t pos = 1;
-    for (size_t i = 0; i < nr_slots; i++) {
-      const uint64_t index1 = (pos - 1) >> 1, index2 = (m - pos - 1) >> 1;
-      matrix_reps_index_map_[i] = (uint32_t)yell::math::reverse_bits(index1, logn);
-      matrix_reps_index_map_[nr_slots | i] = (uint32_t)yell::math::reverse_bits(index2, logn);
-      pos = (pos * generator) & (m - 1);
+  explicit Encoder() : point_(degree), omega_(nr_slots), twist_(degree) {
+    const size_t two_n = degree << 1u;
+    size_t power = 1;  // 3^j mod 2N
+    for (size_t j = 0; j < nr_slots; ++j) {
+      point_[j] = (uint32_t)((power - 1) >> 1);
+      point_[nr_slots + j] = (uint32_t)((two_n - power - 1) >> 1);
+      power = (power * 3) & (two_n - 1);
     }
-    const double PI_ = 3.14159265358979323846;
-    const cplx psi{std::cos((2 * PI_) / (double)m), std::sin((2 * PI_) / (double)m)};
-    for (size_t i = 0; i < degree; i++) {
-      roots_[i] = std::pow(psi, (double)yell::math::reverse_bits(i, logn));
-      inv_roots_[i] = 1.0 / roots_[i];
-    }
+    const double pi = std::acos(-1.0);
+    for (size_t k = 0; k < nr_slots; ++k) omega_[k] = std::polar(1.0, 2.0 * pi * (double)k / (double)degree);
+    for (size_t d = 0; d < degree; ++d) twist_[d] = std::polar(1.0, pi * (double)d / (double)degree);
   }
   ~Encoder() {}
 
   void encode(context::poly_t *msg, std::vector<cplx> const &values, const double scale = context::encoder_scale) const {  // encoder.cpp:116-147
     if (!msg) return;
-    const std::vector<cplx> conj_values{apply_ifft(values)};
+    const std::vector<cplx> conj_values{coefficients_times_n(values)};
     const double delta = scale / (double)degree;
     for (size_t cm = 0; cm < msg->moduli_count(); ++cm) {
       const T P = yell::params::P[cm];
@@ -180,9 +172,10 @@ struct Encoder {
       else val = big_to_double(x);
       res[i].real(val * inv_prec);
     }
-    FFT_inplace(res);
+    for (size_t d = 0; d < degree; ++d) res[d] *= twist_[d];
+    cyclic_dft(res, false);  // res[k] = m(zeta^(2k+1))
     rop->resize(nr_slots);
-    for (size_t i = 0; i < nr_slots; ++i) (*rop)[i] = res[matrix_reps_index_map_[i]];
+    for (size_t j = 0; j < nr_slots; ++j) (*rop)[j] = res[point_[j]];
   }
   void decode(std::vector<double> *rop, context::poly_t const &msg, double scale_) const {  // :190-199
     if (!rop) return;

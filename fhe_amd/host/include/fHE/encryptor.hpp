@@ -1,43 +1,43 @@
-// fHE/encryptor.hpp — polynomial-level encrypt of reference src/encryptor.cpp:9-37 (host plumbing; NTTs on the GPU).
-// The Encoder overloads (encryptor.cpp:39-64) encode on the host (fHE/encoder.hpp) and then take the same path.
+// fHE/encryptor.hpp — Encryptor with the reference's public shape (include/fHE/encryptor.hpp:11-23).  The three small
+// polynomials (u, e0, e1) are sampled on the host; everything else — three forward NTTs and the two u*pk products of
+// src/encryptor.cpp:15-35 — is ONE device call, fhe_hip_encrypt.
 #pragma once
 #include "fHE/cipher.hpp"
 #include "fHE/encoder.hpp"
 #include "fHE/keys.hpp"
+#include <complex>
 namespace fHE {
 struct Encryptor {
   explicit Encryptor(std::shared_ptr<Encoder> encoder = nullptr) : encoder(encoder) {}
   ~Encryptor() {}
+
+  // msg in the power basis; a message with fewer limbs than the ciphertext contributes its first limb under every prime
   bool encrypt(Cipher *rop, context::poly_t const &msg, PK const &pk) const {
     if (!rop) return false;
-    const size_t msg_moduli = msg.moduli_count(), ctx_moduli = rop->moduli_count();
-    context::poly_t u(ctx_moduli, yell::ZO_dist());
-    u.forward();
-    rop->bx.set(context::gauss_struct(&context::fg_prng));  // e0
-    if (msg_moduli == ctx_moduli) {
-      (rop->bx) += msg;  // e0 + msg in the power basis
-    } else {
-      yell::ops::addmod addmod;
-      for (size_t cm = 0; cm < ctx_moduli; ++cm) {
-        auto msg_ptr = msg.cptr_at(0);  // use the first moduli only
-        auto bx_ptr = rop->bx.ptr_at(cm);
-        for (size_t d = 0; d < context::degree; ++d) addmod.compute(*bx_ptr++, *msg_ptr++, cm);
-      }
+    const size_t Li = rop->moduli_count(), n = context::degree, have = msg.moduli_count();
+    if (Li == 0 || have == 0 || Li > pk.bx.moduli_count()) return false;
+    context::poly_t u(Li, yell::ZO_dist());
+    context::poly_t e0m(Li, context::gauss_struct(&context::fg_prng));
+    context::poly_t e1(Li, context::gauss_struct(&context::fg_prng));
+    for (size_t m = 0; m < Li; ++m) {  // e0 + msg, still in the power basis
+      const detail::word p = yell::params::P[m], *src = msg.cptr_at(have == Li ? m : 0);
+      detail::word *dst = e0m.ptr_at(m);
+      for (size_t d = 0; d < n; ++d) { const detail::word t = dst[d] + src[d] % p; dst[d] = t >= p ? t - p : t; }
     }
-    rop->bx.forward_lazy();
-    rop->bx.add_product_of(u, pk.bx);  // ctx.bx = u * pk.bx + e0 + msg
-    rop->ax.set(context::gauss_struct(&context::fg_prng));  // e1
-    rop->ax.forward_lazy();
-    rop->ax.add_product_of(u, pk.ax);  // ctx.ax = u * pk.ax + e1
+    std::vector<detail::word> ct(2 * Li * n);
+    if (fhe_hip_encrypt(yell::runtime::get().ctx, ct.data(), u.cptr_at(0), e0m.cptr_at(0), e1.cptr_at(0), pk.bx.cptr_at(0), pk.ax.cptr_at(0),
+                        (uint32_t)Li, 1, FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
+    std::copy(ct.begin(), ct.begin() + Li * n, rop->bx.ptr_at(0));
+    std::copy(ct.begin() + Li * n, ct.end(), rop->ax.ptr_at(0));
+    u.clear(); e0m.clear(); e1.clear();
     return true;
   }
-  bool encrypt(Cipher *rop, double const &value, PK const &pk) const { return encrypt(rop, std::vector<double>(1, value), pk); }  // :39-42
-  bool encrypt(Cipher *rop, std::vector<double> const &values, PK const &pk) const { return encrypt_values(rop, values, pk); }  // :44-52
-  bool encrypt(Cipher *rop, std::vector<std::complex<double>> const &values, PK const &pk) const { return encrypt_values(rop, values, pk); }  // :54-64
+  bool encrypt(Cipher *rop, double const &value, PK const &pk) const { return encode_then_encrypt(rop, std::vector<double>{value}, pk); }
+  bool encrypt(Cipher *rop, std::vector<double> const &values, PK const &pk) const { return encode_then_encrypt(rop, values, pk); }
+  bool encrypt(Cipher *rop, std::vector<std::complex<double>> const &values, PK const &pk) const { return encode_then_encrypt(rop, values, pk); }
 
  private:
-  template <class V>
-  bool encrypt_values(Cipher *rop, V const &values, PK const &pk) const {
+  template <class Values> bool encode_then_encrypt(Cipher *rop, Values const &values, PK const &pk) const {
     if (!rop || !encoder) return false;
     context::poly_t plain(context::nr_ctxt_moduli);
     encoder->encode(&plain, values, context::encoder_scale);

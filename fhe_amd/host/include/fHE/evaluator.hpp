@@ -11,33 +11,64 @@ namespace fHE {
 struct Evaluator {
  private:
   std::shared_ptr<Encoder> encoder;
-  mutable const MultKey *loaded_mkey_ = nullptr;
-  mutable std::unordered_map<size_t, const RotKey *> loaded_rkeys_;
-  mutable std::unordered_map<size_t, const MixedRotKey *> loaded_mixed_;
   using T = yell::params::value_type;
 
   static fhe_hip_ctx *ctx() { return yell::runtime::get().ctx; }
   static void pack(std::vector<T> &buf, size_t off, context::poly_t const &p, size_t n) { std::memcpy(buf.data() + off, p.cptr_at(0), n * context::degree * sizeof(T)); }
-  bool ensure_mult_key(MultKey const &mkey) const {
-    if (loaded_mkey_ == &mkey) return true;
+  // Which key a device context holds is recorded with the context (yell::runtime), under the key object's process-unique
+  // id: Evaluators that share a context, keys that alternate, and a key built at the address of a destroyed one are all
+  // told apart; whenever the record does not prove the key is there, it is uploaded again.
+  static bool ensure_mult_key(MultKey const &mkey) {
+    auto &held = yell::runtime::get().keys();
+    if (held.mult == mkey.id) return true;
     const size_t L = context::nr_ctxt_moduli, N = context::degree;
     std::vector<T> beta(L * L * N), alpha(L * L * N);
     for (size_t j = 0; j < L; ++j) { pack(beta, j * L * N, *mkey.get_beta_at(j), L); pack(alpha, j * L * N, *mkey.get_alpha_at(j), L); }
+    held.mult = 0;
     if (fhe_hip_load_mult_key(ctx(), beta.data(), alpha.data(), FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
-    loaded_mkey_ = &mkey;
+    held.mult = mkey.id;
     return true;
   }
-  bool ensure_rot_key(RotKey const &rkey) const {
-    auto it = loaded_rkeys_.find(rkey.galois);
-    if (it != loaded_rkeys_.end() && it->second == &rkey) return true;
+  static bool ensure_rot_key(RotKey const &rkey) {
+    auto &held = yell::runtime::get().keys();
+    auto it = held.rot.find(rkey.galois);
+    if (it != held.rot.end() && it->second == rkey.id) return true;
+    held.rot.erase(rkey.galois);
     if (fhe_hip_load_rot_key(ctx(), rkey.galois, rkey.beta.cptr_at(0), rkey.alpha.cptr_at(0), FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
-    loaded_rkeys_[rkey.galois] = &rkey;
+    held.rot[rkey.galois] = rkey.id;
+    return true;
+  }
+  static bool ensure_mixed_key(MixedRotKey const &rkey) {
+    auto &held = yell::runtime::get().keys();
+    auto it = held.mixed.find(rkey.galois);
+    if (it != held.mixed.end() && it->second == rkey.id) return true;
+    held.mixed.erase(rkey.galois);
+    const size_t L = context::nr_ctxt_moduli, N = context::degree;
+    std::vector<T> beta(L * (L + 1) * N), alpha(L * (L + 1) * N);
+    for (size_t j = 0; j < L; ++j) { pack(beta, j * (L + 1) * N, *rkey.get_beta_at(j), L + 1); pack(alpha, j * (L + 1) * N, *rkey.get_alpha_at(j), L + 1); }
+    if (fhe_hip_load_mixed_rot_key(ctx(), rkey.galois, beta.data(), alpha.data(), FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
+    held.mixed[rkey.galois] = rkey.id;
+    return true;
+  }
+  static bool canonical_or_complain(Cipher const *c, const char *what) {
+    if (c->canonical()) return true;
+    std::cerr << "Can only " << what << " canonical ciphertext, call relinearize first." << std::endl;
+    return false;
+  }
+  // one key switch per set bit of `left` (a left rotation by `left` slots), lowest bit first, with the power-of-two keys of the set
+  template <class RotKeyT, class Apply> static bool walk_set_bits(size_t left, RotKeySet<RotKeyT> const &rkeys, Apply const &apply) {
+    while (left) {
+      const size_t step = left & (~left + 1);  // lowest set bit
+      RotKeyT const *key = rkeys.get((uint16_t)step);
+      if (!key) { std::cerr << "No such rotation key for offset " << step << "\n"; return false; }
+      if (!apply(*key)) return false;
+      left ^= step;
+    }
     return true;
   }
 
   bool rotate_with(Cipher *rop, RotKey const &rkey, bool non_ntt) const {
-    if (!rop) return false;
-    if (!rop->canonical()) { std::cerr << "Can only rotate canonical ciphertext, call relinearize first." << std::endl; return false; }
+    if (!rop || !canonical_or_complain(rop, "rotate")) return false;
     if (rkey.galois == 0) return true;
     const size_t Li = rop->moduli_count(), N = context::degree, limbs = Li * N;
     if (Li > context::nr_ctxt_moduli) throw std::invalid_argument("Too many moduli.");
@@ -143,17 +174,10 @@ struct Evaluator {
 
   //! MixedRotKey variant (evaluator.cpp:148-156, 313-325, 403-516)
   bool rotate_slots(Cipher *rop, MixedRotKey const &rkey) const {
-    if (!rop) return false;
-    if (!rop->canonical()) { std::cerr << "Can only rotate canonical ciphertext, call relinearize first." << std::endl; return false; }
+    if (!rop || !canonical_or_complain(rop, "rotate")) return false;
     if (rkey.galois == 0) return true;
-    const size_t Li = rop->moduli_count(), N = context::degree, limbs = Li * N, L = context::nr_ctxt_moduli;
-    auto it = loaded_mixed_.find(rkey.galois);
-    if (it == loaded_mixed_.end() || it->second != &rkey) {
-      std::vector<T> beta(L * (L + 1) * N), alpha(L * (L + 1) * N);
-      for (size_t j = 0; j < L; ++j) { pack(beta, j * (L + 1) * N, *rkey.get_beta_at(j), L + 1); pack(alpha, j * (L + 1) * N, *rkey.get_alpha_at(j), L + 1); }
-      if (fhe_hip_load_mixed_rot_key(ctx(), rkey.galois, beta.data(), alpha.data(), FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
-      loaded_mixed_[rkey.galois] = &rkey;
-    }
+    const size_t Li = rop->moduli_count(), N = context::degree, limbs = Li * N;
+    if (!ensure_mixed_key(rkey)) return false;
     std::vector<T> ct(2 * limbs);
     pack(ct, 0, rop->bx, Li); pack(ct, limbs, rop->ax, Li);
     if (fhe_hip_rotate_mixed(ctx(), rkey.galois, ct.data(), (uint32_t)Li, 1, FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
@@ -162,62 +186,38 @@ struct Evaluator {
     return true;
   }
 
-  //! Rotation with arbitrary offset: binary decomposition over power-of-two keys (evaluator.cpp:158-208)
+  //! Rotation by an arbitrary offset (reference src/evaluator.cpp:158-208): offset > 0 rotates left by offset slots, offset < 0
+  //! right by |offset|, i.e. left by offset mod N/2; one key switch per set bit of that number with the set's power-of-two keys.
   template <class RotKeyT> bool rotate_slots(Cipher *rop, int offset, RotKeySet<RotKeyT> const &rkeys) const {
-    if (!rop) return false;
-    if (!rop->canonical()) { std::cerr << "Can only rotate canonical ciphertext, call relinearize first." << std::endl; return false; }
-    const size_t nr_slots = context::degree >> 1u;
-    bool sign = offset < 0;
-    offset = std::abs(offset) % (int)nr_slots;
-    if (sign) offset = (int)nr_slots - offset;
-    int steps = (int)(std::log2((double)offset) + 1);
-    for (int i = 0; i < steps; ++i) {
-      if (offset & (1 << i)) {
-        auto rotkey = rkeys.get((uint16_t)(1 << i));
-        if (!rotkey) { std::cerr << "No such rotation key for offset " << (1 << i) << "\n"; return false; }
-        rotate_slots(rop, *rotkey);
-      }
-    }
-    return true;
+    if (!rop || !canonical_or_complain(rop, "rotate")) return false;
+    const long slots = (long)(context::degree >> 1);
+    const size_t left = (size_t)((((long)offset % slots) + slots) % slots);
+    return walk_set_bits(left, rkeys, [&](RotKeyT const &key) { return rotate_slots(rop, key); });
   }
-  //! evaluator.cpp:210-232 (no sign handling there: |offset| mod nr_slots)
+  //! Power-basis variant (reference src/evaluator.cpp:210-232); there the sign of the offset is ignored: |offset| mod N/2.
   template <class RotKeyT> bool rotate_slots_non_ntt(Cipher *rop, int offset, RotKeySet<RotKeyT> const &rkeys) const {
-    if (!rop) return false;
-    if (!rop->canonical()) { std::cerr << "Can only rotate canonical ciphertext, call relinearize first." << std::endl; return false; }
-    const size_t nr_slots = context::degree >> 1u;
-    offset = std::abs(offset) % (int)nr_slots;
-    if (offset == 0) return true;
-    const int steps = (int)(std::log2((double)offset) + 1);
-    for (int i = 0; i < steps; ++i) {
-      if (offset & (1 << i)) {
-        RotKeyT const *rotkey = rkeys.get((uint16_t)(1 << i));
-        if (!rotkey) { std::cerr << "No such rotation key for offset " << (1 << i) << "\n"; return false; }
-        rotate_slots_non_ntt(rop, *rotkey);
-      }
-    }
-    return true;
+    if (!rop || !canonical_or_complain(rop, "rotate")) return false;
+    const size_t left = (size_t)(offset < 0 ? -(long)offset : (long)offset) % (context::degree >> 1);
+    return walk_set_bits(left, rkeys, [&](RotKeyT const &key) { return rotate_slots_non_ntt(rop, key); });
   }
 
-  //! Replicate the slot at [pos] into every slot: one masking and log2(N/2) rotate-and-adds above the power basis
-  //! (evaluator.cpp:234-267).
+  //! Replicate the slot at [pos] into every slot (reference src/evaluator.cpp:234-267): keep that slot alone by a plaintext
+  //! mask, then double the number of copies log2(N/2) times, ct += rot(ct, 2^i), all in the power basis.
   template <class RotKeyT> bool replicate(Cipher *rop, size_t pos, RotKeySet<RotKeyT> const &rkeys) const {
-    if (!rop || !encoder) return false;
-    if (!rop->canonical()) { std::cerr << "Can only replicate canonical ciphertext, call relinearize first." << std::endl; return false; }
-    const size_t nr_slots = context::degree >> 1, logn = yell::runtime::get().logn - 1;
-    pos %= nr_slots;
-    std::vector<double> mask(nr_slots, 0.);
-    mask[pos] = 1.;
-    const double scale = context::encoder_scale / 8.;
-    context::poly_t mask_poly(rop->moduli_count());
-    encoder->encode(&mask_poly, mask, scale);
-    mask_poly.forward_lazy();
-    multiply_plain(rop, mask_poly, scale);
+    if (!rop || !encoder || !canonical_or_complain(rop, "replicate")) return false;
+    const size_t slots = context::degree >> 1;
+    const double mask_scale = context::encoder_scale / 8.;
+    std::vector<double> one_hot(slots, 0.);
+    one_hot[pos % slots] = 1.;
+    context::poly_t mask(rop->moduli_count());
+    encoder->encode(&mask, one_hot, mask_scale);
+    mask.forward_lazy();
+    if (!multiply_plain(rop, mask, mask_scale)) return false;
     rop->bx.backward();
     rop->ax.backward();
-    for (size_t i = 0; i < logn; ++i) {
-      fHE::Cipher tmp(*rop);
-      rotate_slots_non_ntt(&tmp, 1 << i, rkeys);
-      add(rop, tmp);  // add is also ok on the power-basis.
+    for (size_t span = 1; span < slots; span <<= 1) {
+      Cipher shifted(*rop);
+      if (!rotate_slots_non_ntt(&shifted, (int)span, rkeys) || !add(rop, shifted)) return false;  // limb-wise add: basis-agnostic
     }
     rop->bx.forward();
     rop->ax.forward();

@@ -1,40 +1,34 @@
-// fHE/mult_key.hpp — reference include/fHE/mult_key.hpp:5-38 + src/mult_key.cpp:3-30.
+// fHE/mult_key.hpp — relinearisation key with the reference's public shape (include/fHE/mult_key.hpp:5-38): L pairs
+// (beta_j, alpha_j) of L-limb polynomials, beta_j = -(e_j + alpha_j s) + s^2 on limb j only (RNS-digit key, no special prime).
 #pragma once
-#include "fHE/context.hpp"
 #include "fHE/keys.hpp"
 #include <vector>
 namespace fHE {
-struct MultKey {
+struct MultKey : detail::pinned_object {
  private:
   using poly_t = context::poly_t;
-  std::vector<poly_t> alpha;  // L polynomials of L moduli
-  std::vector<poly_t> beta;
+  std::vector<poly_t> alpha, beta;
 
  public:
+  const uint64_t id = detail::fresh_key_id();
   explicit MultKey(SK const &sk) {
-    const size_t degree = context::degree, L = context::nr_ctxt_moduli;
-    for (size_t j = 0; j < L; ++j) { alpha.emplace_back(L, yell::uniform{}); beta.emplace_back(L); }
-    auto sx_square(sk.sx);
-    sx_square *= sk.sx;
+    const size_t L = context::nr_ctxt_moduli, n = context::degree;
+    alpha.reserve(L); beta.reserve(L);
+    std::vector<detail::word> s_squared(n);
     for (size_t j = 0; j < L; ++j) {
-      poly_t *beta_ = get_beta_at(j);
-      const poly_t *alpha_ = get_alpha_at(j);
-      beta_->set(context::gauss_struct(&context::fg_prng));
-      beta_->forward();
-      beta_->add_product_of(*alpha_, sk.sx);
-      beta_->negate();  // -e - alpha * sx
-      yell::ops::addmod addmod;  // + [sx^2] on limb j only (mult_key.cpp:19-27)
-      auto sx2_ptr = sx_square.cptr_at(j);
-      auto beta_ptr = beta_->ptr_at(j);
-      for (size_t d = 0; d < degree; ++d) addmod.compute(*beta_ptr++, *sx2_ptr++, j);
+      alpha.emplace_back(L, yell::uniform{});
+      beta.emplace_back(L);
+      detail::mask_with_secret(beta[j], alpha[j], sk.view());
+      const detail::word p = yell::params::P[j], *s = sk.sx.cptr_at(j);
+      for (size_t d = 0; d < n; ++d) s_squared[d] = (detail::word)(((detail::wide)s[d] * s[d]) % p);
+      detail::add_scaled_limb(beta[j], j, 1, s_squared.data());
     }
-    sx_square.clear();
+    std::fill(s_squared.begin(), s_squared.end(), 0);
   }
-  MultKey(MultKey const &) = delete; MultKey(MultKey &&) = delete; MultKey &operator=(MultKey const &) = delete;
-  ~MultKey() {}
-  const poly_t *get_beta_at(size_t j) const { return &beta.at(j); }
-  const poly_t *get_alpha_at(size_t j) const { return &alpha.at(j); }
+  // pair j of the key: beta_j / alpha_j, L limbs each, NTT basis
+  poly_t const *get_beta_at(size_t j) const { return &beta.at(j); }
   poly_t *get_beta_at(size_t j) { return &beta.at(j); }
+  poly_t const *get_alpha_at(size_t j) const { return &alpha.at(j); }
   poly_t *get_alpha_at(size_t j) { return &alpha.at(j); }
 };
 }  // namespace fHE

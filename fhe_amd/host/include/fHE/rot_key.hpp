@@ -1,140 +1,100 @@
-// fHE/rot_key.hpp — RotKey / RotKeySet of reference include/fHE/rot_key.hpp:9-39,84-118 + src/rot_key.cpp:6-79.
+// fHE/rot_key.hpp — rotation keys with the reference's public shape (include/fHE/rot_key.hpp:9-118):
+//   RotKey      beta, alpha over L + K moduli, beta = -(e + alpha s) + P sigma_g(s) on the normal limbs (P = product of the special primes)
+//   MixedRotKey L pairs over L + 1 moduli (one special prime q_K), beta_j = -(e_j + alpha_j s) + q_K sigma_g(s) on limb j only
+//   RotKeySet   left-rotation keys for the offsets 1, 2, 4, ..., N/4
+// sigma_g = X -> X^g, g = 3^k mod 2N for a left rotation by k slots.
 #pragma once
-#include "fHE/context.hpp"
 #include "fHE/keys.hpp"
 #include "fHE/yell.hpp"
-#include <unordered_map>
+#include <memory>
+#include <vector>
 namespace fHE {
-inline size_t rotation_offset_galois(int offset) {  // rot_key.cpp:6-21
-  const size_t nr_slots = context::degree >> 1u, m = context::degree << 1u;
-  bool sign = offset > 0;
-  offset = std::abs(offset) % (int)nr_slots;
-  if (sign) offset = (int)nr_slots - offset;
-  size_t galois{1};
-  while (offset--) { galois *= 3; galois &= (m - 1); }
-  return galois;
-}
-struct RotKey {
- private:
-  void lift_normal_moduli(context::poly_t *op) const {  // [x] -> [P * x] on the normal moduli (rot_key.cpp:64-79)
-    const size_t L = context::nr_ctxt_moduli, K = context::nr_sp_primes, degree = context::degree;
-    if (!op) return;
-    yell::ops::mulmod mulmod;
-    std::vector<size_t> sp_primes(K);
-    std::iota(sp_primes.begin(), sp_primes.end(), context::index_sp_prime(0));
-    for (size_t cm = 0; cm < L; ++cm) {
-      auto P_mod_qj = product_of(sp_primes.begin(), sp_primes.end(), cm);
-      auto dst = op->ptr_at(cm);
-      for (size_t d = 0; d < degree; ++d) mulmod.compute(*dst++, P_mod_qj, cm);
-    }
+// galois element of a rotation: offset <= 0 rotates left by |offset| slots, offset > 0 right by offset (= left by N/2 - offset)
+inline size_t rotation_offset_galois(int offset) {
+  const size_t slots = context::degree >> 1, two_n = context::degree << 1;
+  size_t k = (size_t)(offset < 0 ? -(long)offset : (long)offset) % slots;
+  if (offset > 0) k = slots - k;
+  size_t g = 1, base = 3;  // 3^k mod 2N by squaring
+  for (; k; k >>= 1) {
+    if (k & 1) g = (g * base) & (two_n - 1);
+    base = (base * base) & (two_n - 1);
   }
+  return g;
+}
 
- public:
+namespace detail {
+template <class Dir> inline size_t galois_of(uint16_t offset, Dir dir) { return rotation_offset_galois(dir == Dir::RIGHT ? (int)offset : -(int)offset); }
+// sigma_g(s) on the normal limbs (NTT basis: a permutation, done by the device)
+inline context::poly_t rotated_secret(SK const &sk, size_t galois) {
+  context::poly_t r(sk.sx);
+  apply_galois(&r, galois);
+  return r;
+}
+}  // namespace detail
+
+struct RotKey : detail::pinned_object {
   enum class Direction { LEFT, RIGHT };
   const size_t galois;
   context::poly_t beta;   //! L + K moduli
   context::poly_t alpha;  //! L + K moduli
+  const uint64_t id = detail::fresh_key_id();
 
   explicit RotKey(SK const &sk, uint16_t offset, Direction dir)
-      : galois(rotation_offset_galois(dir == Direction::RIGHT ? offset : -(int)offset)),
+      : galois(detail::galois_of(offset, dir)),
         beta(context::nr_ctxt_moduli + context::nr_sp_primes),
         alpha(context::nr_ctxt_moduli + context::nr_sp_primes, yell::uniform{}) {
-    using T = yell::params::value_type; using gT = yell::params::gt_value_type;
-    const size_t L = context::nr_ctxt_moduli, K = context::nr_sp_primes, degree = context::degree;
-    auto rotated_sx(sk.sx);
-    apply_galois(&rotated_sx, galois);
-    lift_normal_moduli(&rotated_sx);
-    beta.set(context::gauss_struct(&context::fg_prng));  // reuse beta as the 'e'
-    beta.forward_lazy();
-    for (size_t cm = 0; cm < L + K; ++cm) {
-      auto bptr = beta.ptr_at(cm);
-      auto aptr = alpha.cptr_at(cm);
-      auto sptr = cm < L ? sk.sx.cptr_at(cm) : sk.ext_sx.cptr_at(cm - L);
-      for (size_t d = 0; d < degree; ++d) {
-        gT tmp = (gT)(*aptr++) * (*sptr++) + *bptr;
-        yell::ops::barret_reduction(&tmp, cm);
-        *bptr++ = (T)tmp;
-      }
-    }
-    beta.negate();
-    yell::ops::addmod addmod;  // + P * s'
-    for (size_t cm = 0; cm < L; ++cm) {
-      auto op0 = beta.ptr_at(cm);
-      auto op1 = rotated_sx.cptr_at(cm);
-      for (size_t d = 0; d < degree; ++d) addmod.compute(*op0++, *op1++, cm);
-    }
-    rotated_sx.clear();
+    const size_t L = context::nr_ctxt_moduli, K = context::nr_sp_primes;
+    detail::mask_with_secret(beta, alpha, sk.view());
+    context::poly_t turned = detail::rotated_secret(sk, galois);
+    for (size_t m = 0; m < L; ++m) detail::add_scaled_limb(beta, m, detail::special_product_mod(L, K, m), turned.cptr_at(m));
+    turned.clear();
   }
-  RotKey(RotKey const &) = delete; RotKey(RotKey &&) = delete; RotKey &operator=(RotKey const &) = delete;
-  ~RotKey() {}
 };
 
-// MixedRotKey (reference include/fHE/rot_key.hpp:41-82, src/rot_key.cpp:81-120): digit-decomposed rotation key with
-// ONE special prime; L polynomials of L + 1 moduli each.
-struct MixedRotKey {
+struct MixedRotKey : detail::pinned_object {
  private:
   using poly_t = context::poly_t;
-  std::vector<poly_t> alpha;  // L polynomials, each L + 1 moduli
-  std::vector<poly_t> beta;
+  std::vector<poly_t> alpha, beta;  // L polynomials of L + 1 moduli each (limb L under the first special prime)
 
  public:
   enum class Direction { LEFT, RIGHT };
   const size_t galois;
+  const uint64_t id = detail::fresh_key_id();
 
-  explicit MixedRotKey(SK const &sk, uint16_t offset, Direction dir)
-      : galois(rotation_offset_galois(dir == Direction::RIGHT ? offset : -(int)offset)) {
-    using T = yell::params::value_type;
-    const size_t L = context::nr_ctxt_moduli, degree = context::degree, bytes = degree * sizeof(T);
-    for (size_t j = 0; j < L; ++j) { beta.emplace_back(L + 1); alpha.emplace_back(L + 1, yell::uniform{}); }
-    context::poly_t ext_sx(L + 1);
-    for (size_t j = 0; j < L + 1; ++j) std::memcpy(ext_sx.ptr_at(j), j < L ? sk.sx.cptr_at(j) : sk.ext_sx.cptr_at(0), bytes);
-    auto rotated_sx(ext_sx);
-    apply_galois(&rotated_sx, galois);
-    // beta_j = -sx * alpha_j + [qK]_qj * rotated(sx) + e   (rot_key.cpp:99-117)
-    yell::ops::muladd muladd;
-    const T qK = yell::params::P[context::index_sp_prime(0)];
+  explicit MixedRotKey(SK const &sk, uint16_t offset, Direction dir) : galois(detail::galois_of(offset, dir)) {
+    const size_t L = context::nr_ctxt_moduli;
+    context::poly_t turned = detail::rotated_secret(sk, galois);
+    alpha.reserve(L); beta.reserve(L);
     for (size_t j = 0; j < L; ++j) {
-      poly_t *beta_ = get_beta_at(j);
-      const poly_t *alpha_ = get_alpha_at(j);
-      beta_->set(context::gauss_struct(&context::fg_prng));
-      beta_->forward();
-      beta_->add_product_of(*alpha_, ext_sx);
-      beta_->negate();
-      const T qK_j = qK % yell::params::P[j];
-      auto b = beta_->ptr_at(j);
-      auto s = rotated_sx.cptr_at(j);
-      for (size_t d = 0; d < degree; ++d) b[d] = muladd(b[d], s[d], qK_j, j);
+      alpha.emplace_back(L + 1, yell::uniform{});
+      beta.emplace_back(L + 1);
+      detail::mask_with_secret(beta[j], alpha[j], sk.view());  // modulus L is the special prime: SecretView hands out ext_sx there
+      detail::add_scaled_limb(beta[j], j, detail::special_product_mod(L, 1, j), turned.cptr_at(j));
     }
-    rotated_sx.clear(); ext_sx.clear();
+    turned.clear();
   }
-  MixedRotKey(MixedRotKey const &) = delete; MixedRotKey(MixedRotKey &&) = delete; MixedRotKey &operator=(MixedRotKey const &) = delete;
   const poly_t *get_beta_at(size_t j) const { return &beta.at(j); }
   const poly_t *get_alpha_at(size_t j) const { return &alpha.at(j); }
   poly_t *get_beta_at(size_t j) { return &beta.at(j); }
   poly_t *get_alpha_at(size_t j) { return &alpha.at(j); }
-  ~MixedRotKey() {}
 };
 
-template <class RotKeyType> struct RotKeySet {
+template <class RotKeyType> struct RotKeySet : detail::pinned_object {
  private:
-  using rotkey_ptr = std::shared_ptr<RotKeyType>;
-  std::unordered_map<size_t, rotkey_ptr> rot_keys;
-  size_t logn;
+  std::vector<std::unique_ptr<RotKeyType>> by_log2_;  // entry i: left rotation by 2^i slots
 
  public:
-  //! log(N/2) left-rotation keys for offsets 1, 2, 4, ... (rot_key.hpp:94-100)
-  explicit RotKeySet(SK const &sk) : logn(yell::runtime::get().logn - 1) {
-    for (size_t i = 0; i < logn; ++i) {
-      int idx = 1 << i;
-      rot_keys.insert({(size_t)idx, std::make_shared<RotKeyType>(sk, (uint16_t)idx, RotKeyType::Direction::LEFT)});
-    }
+  explicit RotKeySet(SK const &sk) {
+    const size_t count = yell::runtime::get().logn - 1;  // log2(N/2) keys
+    by_log2_.reserve(count);
+    for (size_t i = 0; i < count; ++i) by_log2_.emplace_back(new RotKeyType(sk, (uint16_t)(1u << i), RotKeyType::Direction::LEFT));
   }
-  RotKeySet(RotKeySet const &) = delete; RotKeySet(RotKeySet &&) = delete; RotKeySet &operator=(RotKeySet const &) = delete;
+  // the key of a power-of-two offset, or nullptr when the set holds none for it
   const RotKeyType *get(uint16_t offset) const {
-    if (offset >= (1LL << logn)) return nullptr;
-    auto kv = rot_keys.find(offset);
-    return kv == rot_keys.end() ? nullptr : kv->second.get();
+    if (offset == 0 || (offset & (offset - 1))) return nullptr;
+    size_t i = 0;
+    while ((1u << i) < offset) ++i;
+    return i < by_log2_.size() ? by_log2_[i].get() : nullptr;
   }
-  ~RotKeySet() {}
 };
 }  // namespace fHE

@@ -16,6 +16,7 @@
 #include <memory>
 #include <numeric>
 #include <stdexcept>
+#include <unordered_map>
 #include <vector>
 
 #include "fhe_hip.h"
@@ -35,10 +36,18 @@ struct PrimeTable {
 inline PrimeTable P;
 }  // namespace params
 
+// what a device context currently holds: ids of the host key objects last uploaded into it (0 = none).  Kept with the
+// context, not with whoever uploaded: every Evaluator that shares the context sees the same truth.
+struct device_keys {
+  uint64_t mult = 0;
+  std::unordered_map<size_t, uint64_t> rot, mixed;  // by galois element
+};
 // process-wide binding of the yell types to one device context (set by fHE::Context::activate())
 struct runtime {
   fhe_hip_ctx *ctx = nullptr;
   size_t degree = 0, logn = 0;
+  std::unordered_map<fhe_hip_ctx *, device_keys> loaded;
+  device_keys &keys() { return loaded[ctx]; }
   static runtime &get() { static runtime r; return r; }
 };
 inline void check(int rc, const char *what) {

@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <fstream>
+#include <new>
 #include "fHE/context.hpp"
 #include "fHE/cipher.hpp"
 #include "fHE/decryptor.hpp"
@@ -83,6 +84,45 @@ int main(int argc, char **argv) {
     }
     // misuse conventions: relinearize on a canonical ciphertext returns false; rotate of a non-canonical one too
     if (evaluator.relinearize(&ca, mkey)) { std::fprintf(stderr, "relinearize accepted a canonical ciphertext\n"); return 7; }
+
+    // two Evaluators sharing the one device context, two MultKeys used alternately, and a key rebuilt where another one
+    // was destroyed: the device must always relinearise with the key that was passed
+    {
+      fHE::Evaluator other(encoder);
+      fHE::MultKey mkey2(sk);
+      fHE::Cipher r1(in_a), r2(in_a), r3(in_a), r4(in_a);
+      if (!evaluator.multiply_and_relin(&r1, in_b, mkey) || !other.multiply_and_relin(&r2, in_b, mkey2) ||
+          !evaluator.multiply_and_relin(&r3, in_b, mkey) || !other.multiply_and_relin(&r4, in_b, mkey2)) { std::fprintf(stderr, "alternating keys failed\n"); return 28; }
+      const size_t bytes = (L - 1) * N * 8;
+      if (std::memcmp(r1.bx.cptr_at(0), ca.bx.cptr_at(0), bytes) || std::memcmp(r3.bx.cptr_at(0), ca.bx.cptr_at(0), bytes) ||
+          std::memcmp(r2.bx.cptr_at(0), r4.bx.cptr_at(0), bytes) || !std::memcmp(r1.bx.cptr_at(0), r2.bx.cptr_at(0), bytes)) {
+        std::fprintf(stderr, "a stale MultKey was used on the device\n"); return 29;
+      }
+      fHE::context::poly_t d2(L - 1);
+      decryptor.decrypt(&d2, r2, sk);  // the second key is a valid key too: same plaintext up to noise
+      long off = 0;
+      for (size_t d = 0; d < N; ++d) {
+        const T p = yell::params::P[0];
+        const T x = d2.cptr_at(0)[d], y = dec_mul.cptr_at(0)[d], df = x >= y ? x - y : y - x;
+        off = std::max(off, (long)std::min(df, p - df));
+      }
+      if (off > (1L << 40)) { std::fprintf(stderr, "second MultKey decrypts differently (%ld)\n", off); return 30; }
+      alignas(fHE::RotKey) static unsigned char slot[sizeof(fHE::RotKey)];
+      fHE::Cipher q1(in_a), q2(in_a);
+      auto *k1 = new (slot) fHE::RotKey(sk, 1, fHE::RotKey::Direction::LEFT);
+      const bool ok1 = evaluator.rotate_slots(&q1, *k1);
+      k1->~RotKey();
+      auto *k2 = new (slot) fHE::RotKey(sk, 1, fHE::RotKey::Direction::LEFT);  // same address, same galois, different key
+      const bool ok2 = other.rotate_slots(&q2, *k2);
+      fHE::Cipher q3(in_a);
+      fHE::context::poly_t want_b(q2.bx);
+      const bool ok3 = evaluator.rotate_slots(&q3, *k2);
+      k2->~RotKey();
+      if (!ok1 || !ok2 || !ok3 || !std::memcmp(q1.bx.cptr_at(0), q2.bx.cptr_at(0), L * N * 8) || std::memcmp(q3.bx.cptr_at(0), want_b.cptr_at(0), L * N * 8)) {
+        std::fprintf(stderr, "a RotKey rebuilt in place was mistaken for the old one\n"); return 31;
+      }
+      std::printf("key identity: alternating MultKeys and a RotKey rebuilt in place are told apart\n");
+    }
 
     fHE::Cipher rot(in_a);
     if (!evaluator.rotate_slots(&rot, rkey)) { std::fprintf(stderr, "rotate_slots failed\n"); return 8; }

@@ -41,6 +41,8 @@ def test_config1_roundtrip_through_cpp_api(tmp_path, logN, L, K):
     r = subprocess.run([BIN, str(logN), str(L), str(K), path], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "host_roundtrip OK" in r.stdout
+    # two Evaluators on one context alternating two MultKeys, and a RotKey rebuilt at a destroyed key's address
+    assert "key identity: alternating MultKeys and a RotKey rebuilt in place are told apart" in r.stdout
     # CKKS end to end through the Encoder overloads of Encryptor/Decryptor (slot values in -> x*y / rotated x out);
     # floating point: the driver itself enforces < 1e-6 at scale 2^62 and exits non-zero otherwise
     assert "slot-wise product max error" in r.stdout
