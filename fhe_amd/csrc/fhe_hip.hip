@@ -1388,6 +1388,27 @@ int fhe_hip_encrypt(fhe_hip_ctx *c, uint64_t *ct, const uint64_t *u, const uint6
   } catch (...) { return abi_exception(); }
 }
 
+int fhe_hip_debug_violations(fhe_hip_ctx *c, uint64_t *count, uint32_t *first_site, int *enabled) {
+  TRY(check_ctx(c));
+  if (count) *count = 0;
+  if (first_site) *first_site = 0;
+#ifdef FHE_HIP_DEBUG
+  if (enabled) *enabled = 1;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  unsigned long long n = 0; unsigned int site = 0;
+  HIPCHK(c, hipMemcpyFromSymbol(&n, HIP_SYMBOL(fhe_hip_dbg_count), sizeof(n)));
+  HIPCHK(c, hipMemcpyFromSymbol(&site, HIP_SYMBOL(fhe_hip_dbg_first_site), sizeof(site)));
+  if (count) *count = n;
+  if (first_site) *first_site = site;
+  n = 0; site = 0;  // reading resets
+  HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(fhe_hip_dbg_count), &n, sizeof(n)));
+  HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(fhe_hip_dbg_first_site), &site, sizeof(site)));
+#else
+  if (enabled) *enabled = 0;
+#endif
+  return FHE_HIP_OK;
+}
+
 int fhe_hip_profile_enable(fhe_hip_ctx *c, int on) { TRY(check_ctx(c)); c->prof = on != 0; return FHE_HIP_OK; }
 int fhe_hip_profile_reset(fhe_hip_ctx *c) {
   try {

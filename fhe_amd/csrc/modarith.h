@@ -26,6 +26,25 @@ struct PrimeC {
 
 __device__ __forceinline__ u64 mad_wide(u32 a, u32 b, u64 c) { return (u64)a * (u64)b + c; }
 
+// Debug build (make -C fhe_amd/csrc DEBUG=1 -> libfhe_hip_debug.so): residue-range checks compiled into the kernels, the
+// analogue of the reference's non-release -DCHECK_STRICTMOD (CMakeCompilers.txt:26).  A violation is COUNTED (and the first
+// site remembered), never trapped: a trapping kernel faults the GPU.  fhe_hip_debug_violations() reads the counters.
+// Sites: 1 fwd rows in (<4p), 2 fwd rows out (<p), 3 fwd rows epilogue out (<p), 4 inv rows in (<2p), 5 inv rows out (<2p),
+// 6 fwd cols in (<4p), 7 fwd cols out (<4p), 8 inv cols in (<2p), 9 inv cols out (<p), 10 relin out (<p), 11 relin digit in (<4p),
+// 12 rotation special-limb rows out (<2p), 13 bconv out (<p), 14 cross_mult out (<p), 15 key product out (<p), 16 pointwise out (<p).
+#ifdef FHE_HIP_DEBUG
+__device__ unsigned long long fhe_hip_dbg_count = 0;
+__device__ unsigned int fhe_hip_dbg_first_site = 0;
+__device__ __forceinline__ void dbg_range(u64 v, u64 bound, unsigned site) {
+  if (v >= bound) {
+    if (atomicAdd(&fhe_hip_dbg_count, 1ull) == 0) fhe_hip_dbg_first_site = site;
+  }
+}
+#define DBG_RANGE(v, bound, site) dbg_range((v), (bound), (site))
+#else
+#define DBG_RANGE(v, bound, site) ((void)0)
+#endif
+
 // (thi:tlo) * 2^-64 mod p, in (0, 2p) provided thi < p.  With thi < c*p the result is < (c+1)*p.
 template <bool SP>
 __device__ __forceinline__ u64 mont_reduce(u64 thi, u64 tlo, const PrimeC &P) {

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
   u64 e[8], wA[7], wB[7], wC0[3], wC1[3];
   // phase A: spans 128, 64, 32; thread holds {t + 32k}.  All twiddles of the three phases are requested here, behind the data.
 #pragma unroll
-  for (int k = 0; k < 8; ++k) e[k] = s[t + 32 * k];
+  for (int k = 0; k < 8; ++k) { e[k] = s[t + 32 * k]; DBG_RANGE(e[k], 2 * P.twop, 1); }
   load_tw<3>(wA, tw, baseA);
   load_tw<3>(wB, tw, (baseA << 3) + c);
   load_tw<2>(wC0, tw, (baseA << 6) + 2 * t);
@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
     const u32 el = 64 * i + 2 * t;
     const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[row8_pos(el)]);
     if constexpr (EPI == 0) {
+      DBG_RANGE(v.x, P.p, 2); DBG_RANGE(v.y, P.p, 2);
       *reinterpret_cast<ulonglong2 *>(&d[el]) = v;
     } else {
       const u64 off = (u64)l * N + (u64)row * 256 + el;
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
           r0 = csub(r0 + ad.x, P.p); r1 = csub(r1 + ad.y, P.p);
         }
       }
+      DBG_RANGE(r0, P.p, 3); DBG_RANGE(r1, P.p, 3);
       *reinterpret_cast<ulonglong2 *>(&a.epi_out[(u64)b * a.epi_out_bstride + off]) = make_ulonglong2(r0, r1);
     }
   }
@@ -274,6 +276,7 @@ __global__ __launch_bounds__(256) void ntt_rows8_inv_kernel(NttArgs a) {
       v.x = csub(mulmod_full<SP>(k.x, x.x, P) + csub(v.x, P.p), P.p);
       v.y = csub(mulmod_full<SP>(k.y, x.y, P) + csub(v.y, P.p), P.p);
     }
+    DBG_RANGE(v.x, P.twop, 4); DBG_RANGE(v.y, P.twop, 4);
     *reinterpret_cast<ulonglong2 *>(&L[row8_pos(el)]) = v;
   }
   wave_lds_sync();
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(256) void ntt_rows8_inv_kernel(NttArgs a) {
   for (int k = 0; k < 8; ++k) e[k] = L[k * 36 + t];
   inv_phase<SP, 3>(e, tw, baseA, P);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) d[t + 32 * k] = e[k];
+  for (int k = 0; k < 8; ++k) { DBG_RANGE(e[k], P.twop, 5); d[t + 32 * k] = e[k]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(256) void rot_special_rows8_kernel(RotSpArgs a) {
     inv_phase<SP, 3>(y, twi, baseA, P);
     u64 *d = (h == 0 ? a.e0 : a.e1) + off;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) d[t + 32 * k] = y[k];
+    for (int k = 0; k < 8; ++k) { DBG_RANGE(y[k], P.twop, 12); d[t + 32 * k] = y[k]; }
   }
 }
 
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs
         const u32 slot = tid + rep * T, g = slot / CT, c = slot % CT;
         u64 e[1 << LA];
 #pragma unroll
-        for (int k = 0; k < (1 << LA); ++k) e[k] = s[(u64)(g + G * k) * 256 + c];
+        for (int k = 0; k < (1 << LA); ++k) { e[k] = s[(u64)(g + G * k) * 256 + c]; DBG_RANGE(e[k], 2 * P.twop, 6); }
         fwd_phase_ua<SP, LA>(e, tw, P);
 #pragma unroll
         for (int k = 0; k < (1 << LA); ++k) lds[(g + G * k) * CS + c] = e[k];
@@ -464,11 +467,12 @@ __global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs
       for (int k = 0; k < (1 << LB); ++k) {
         const u32 row = (u << LB) + k;
         e[k] = (LA > 0) ? lds[row * CS + c] : s[(u64)row * 256 + c];
+        DBG_RANGE(e[k], 2 * P.twop, 6);
       }
       if constexpr (LA > 0) fwd_phase_w<SP, LB>(e, wB[rep], P);
       else fwd_phase<SP, LB>(e, tw, (1u << LA) + u, P);
 #pragma unroll
-      for (int k = 0; k < (1 << LB); ++k) d[(u64)((u << LB) + k) * 256 + c] = e[k];  // lazy [0,4p)
+      for (int k = 0; k < (1 << LB); ++k) { DBG_RANGE(e[k], 2 * P.twop, 7); d[(u64)((u << LB) + k) * 256 + c] = e[k]; }  // lazy [0,4p)
     }
   } else {
 #pragma unroll
@@ -476,13 +480,13 @@ __global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs
       const u32 slot = tid + rep * T, u = slot / CT, c = slot % CT;
       u64 e[1 << LB];
 #pragma unroll
-      for (int k = 0; k < (1 << LB); ++k) e[k] = s[(u64)((u << LB) + k) * 256 + c];
+      for (int k = 0; k < (1 << LB); ++k) { e[k] = s[(u64)((u << LB) + k) * 256 + c]; DBG_RANGE(e[k], P.twop, 8); }
       inv_phase<SP, LB>(e, tw, (1u << LA) + u, P);
 #pragma unroll
       for (int k = 0; k < (1 << LB); ++k) {
         const u32 row = (u << LB) + k;
         if constexpr (LA > 0) lds[row * CS + c] = e[k];
-        else d[(u64)row * 256 + c] = csub(mont_mul<SP>(nscale, e[k], P), P.p);
+        else { const u64 r = csub(mont_mul<SP>(nscale, e[k], P), P.p); DBG_RANGE(r, P.p, 9); d[(u64)row * 256 + c] = r; }
       }
     }
     if constexpr (LA > 0) {
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs
         for (int k = 0; k < (1 << LA); ++k) e[k] = lds[(g + G * k) * CS + c];
         inv_phase<SP, LA>(e, tw, 1u, P);
 #pragma unroll
-        for (int k = 0; k < (1 << LA); ++k) d[(u64)(g + G * k) * 256 + c] = csub(mont_mul<SP>(nscale, e[k], P), P.p);
+        for (int k = 0; k < (1 << LA); ++k) { const u64 r = csub(mont_mul<SP>(nscale, e[k], P), P.p); DBG_RANGE(r, P.p, 9); d[(u64)(g + G * k) * 256 + c] = r; }
       }
     }
   }
@@ -587,6 +591,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] = s[t + 32 * k];
   };
+  [[maybe_unused]] auto check_digit = [&]() {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) DBG_RANGE(x[k], 2 * P.twop, 11);
+  };
   ulonglong2 kb[4], ka[4];
   auto load_keys = [&](u32 j, int q0) {  // two MAC groups (q0, q0 + 1) of digit j
     const u64 koff = ((u64)j * a.klimbs + m) * N + row_off;
@@ -617,6 +625,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
   for (u32 j = 0; j < nd; ++j) {
     const u32 jn = j + 1 < nd ? j + 1 : j;  // the last digit re-requests itself (keeps one code path; results unused)
+#ifdef FHE_HIP_DEBUG
+    check_digit();
+#endif
     if (j == i) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) L[k * 36 + t] = x[k];
@@ -671,6 +682,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     u64 r00 = canon4(acc0[2 * q], P), r01 = canon4(acc0[2 * q + 1], P), r10 = canon4(acc1[2 * q], P), r11 = canon4(acc1[2 * q + 1], P);
     if (c0) { const ulonglong2 d0 = *reinterpret_cast<const ulonglong2 *>(&c0[e]); r00 = csub(r00 + d0.x, P.p); r01 = csub(r01 + d0.y, P.p); }
     if (c1) { const ulonglong2 d1 = *reinterpret_cast<const ulonglong2 *>(&c1[e]); r10 = csub(r10 + d1.x, P.p); r11 = csub(r11 + d1.y, P.p); }
+    DBG_RANGE(r00, P.p, 10); DBG_RANGE(r01, P.p, 10); DBG_RANGE(r10, P.p, 10); DBG_RANGE(r11, P.p, 10);
     *reinterpret_cast<ulonglong2 *>(&o[e]) = make_ulonglong2(r00, r01);
     *reinterpret_cast<ulonglong2 *>(&o[half + e]) = make_ulonglong2(r10, r11);
   }

@@ -9,6 +9,11 @@
 
 __device__ __forceinline__ ulonglong2 ld2(const u64 *p) { return *reinterpret_cast<const ulonglong2 *>(p); }
 __device__ __forceinline__ void st2(u64 *p, u64 x, u64 y) { *reinterpret_cast<ulonglong2 *>(p) = make_ulonglong2(x, y); }
+// store of two canonical residues (debug build: range-checked against the modulus, site = kernel)
+__device__ __forceinline__ void st2c(u64 *p, u64 x, u64 y, [[maybe_unused]] u64 mod, [[maybe_unused]] unsigned site) {
+  DBG_RANGE(x, mod, site); DBG_RANGE(y, mod, site);
+  st2(p, x, y);
+}
 __device__ __forceinline__ u64 addmod_c(u64 a, u64 b, u64 p) { return csub(a + b, p); }
 
 // Mul::cross_mult (src/evaluator.cpp:621-647): c0,c1 = [b][2][Li][N] -> out3 = [b][3][Li][N]
@@ -33,9 +38,9 @@ __global__ __launch_bounds__(PW_THREADS) void cross_mult_kernel(u64 *out3, const
     r1[i] = csub(mont_mul<SP>(P.r2, t, P), P.p);
   }
   const u64 o = ((u64)b * 3 * Li + l) * N + d;
-  st2(out3 + o, r0[0], r0[1]);
-  st2(out3 + o + half, r1[0], r1[1]);
-  st2(out3 + o + 2 * half, r2[0], r2[1]);
+  st2c(out3 + o, r0[0], r0[1], P.p, 14);
+  st2c(out3 + o + half, r1[0], r1[1], P.p, 14);
+  st2c(out3 + o + 2 * half, r2[0], r2[1], P.p, 14);
 }
 
 // internal::do_approximated_basis_conversion (src/base_converter.cpp:313-349), all targets of one
@@ -123,6 +128,7 @@ __global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
   for (int t = 0; t < BCONV_TC; ++t) {
     const PrimeC PT = a.primes[a.tgt_first + tt[t]];
     const u64 r = bconv_fold<SP>(acc[t], PT);
+    DBG_RANGE(r, PT.p, 13);
     if (tbase + t < ntgt) a.out[((u64)e * a.out_limbs + a.out_off + tbase + t) * a.N + d] = r;
   }
 }
@@ -149,8 +155,8 @@ __global__ __launch_bounds__(PW_THREADS) void rot_keymul_kernel(u64 *e0, u64 *e1
     x = ld2(ext + o);
   }
   const ulonglong2 kb = ld2(beta_m + (u64)m * N + d), ka = ld2(alpha_m + (u64)m * N + d);
-  st2(e0 + o, csub(mont_mul<SP>(kb.x, x.x, P), P.p), csub(mont_mul<SP>(kb.y, x.y, P), P.p));
-  st2(e1 + o, csub(mont_mul<SP>(ka.x, x.x, P), P.p), csub(mont_mul<SP>(ka.y, x.y, P), P.p));
+  st2c(e0 + o, csub(mont_mul<SP>(kb.x, x.x, P), P.p), csub(mont_mul<SP>(kb.y, x.y, P), P.p), P.p, 15);
+  st2c(e1 + o, csub(mont_mul<SP>(ka.x, x.x, P), P.p), csub(mont_mul<SP>(ka.y, x.y, P), P.p), P.p, 15);
 }
 
 // fHE::apply_galois (src/yell.cpp:14-24) as a gather through a per-galois index table; out-of-place.
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(PW_THREADS) void add_kernel(u64 *rop, const u64 *op
   const u64 p = primes[blockIdx.y].p;
   const u64 o = ((u64)blockIdx.z * gridDim.y + blockIdx.y) * N + d;
   const ulonglong2 a = ld2(rop + o), b = ld2(op + o);
-  st2(rop + o, addmod_c(a.x, b.x, p), addmod_c(a.y, b.y, p));
+  st2c(rop + o, addmod_c(a.x, b.x, p), addmod_c(a.y, b.y, p), p, 16);
 }
 
 // Evaluator::multiply_plain (src/evaluator.cpp:97-106): ct = [b][2][nl][N] *= pt [nl][N]
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(PW_THREADS) void mul_plain_kernel(u64 *ct, const u6
   const PrimeC P = primes[l];
   const u64 o = ((u64)blockIdx.z * gridDim.y + blockIdx.y) * N + d;
   const ulonglong2 x = ld2(ct + o), y = ld2(pt + (u64)l * N + d);
-  st2(ct + o, mulmod_full<SP>(y.x, x.x, P), mulmod_full<SP>(y.y, x.y, P));
+  st2c(ct + o, mulmod_full<SP>(y.x, x.x, P), mulmod_full<SP>(y.y, x.y, P), P.p, 16);
 }
 
 // key upload: x -> x * 2^64 mod p in place; limb l uses midx[l % mper]

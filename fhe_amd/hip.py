@@ -85,6 +85,7 @@ def load_library():
         "fhe_hip_batch_run": (i, [C.POINTER(vp), u32, i, vp, vp, vp, u64, u32, sz, i]),
         "fhe_hip_mul_relin_rescale_noalloc": (i, [vp, vp, vp, vp, u32, sz]),
         "fhe_hip_set_tuning": (i, [vp, i, u64]),
+        "fhe_hip_debug_violations": (i, [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(i)]),
         "fhe_hip_profile_enable": (i, [vp, i]),
         "fhe_hip_profile_reset": (i, [vp]),
         "fhe_hip_profile_get": (i, [vp, C.POINTER(C.c_char_p), C.POINTER(u64), C.POINTER(C.c_double), i]),
@@ -102,7 +103,7 @@ EXPORTED_SYMBOLS = [
     "fhe_hip_mod_up", "fhe_hip_mod_down", "fhe_hip_rescale", "fhe_hip_load_mult_key", "fhe_hip_load_rot_key",
     "fhe_hip_add", "fhe_hip_multiply_plain", "fhe_hip_cross_mult", "fhe_hip_relin_only", "fhe_hip_relinearize",
     "fhe_hip_mul_relin_rescale", "fhe_hip_rotate", "fhe_hip_rotate_non_ntt", "fhe_hip_load_mixed_rot_key", "fhe_hip_rotate_mixed", "fhe_hip_decrypt", "fhe_hip_encrypt", "fhe_hip_profile_enable", "fhe_hip_profile_reset",
-    "fhe_hip_profile_get", "fhe_hip_batch_run", "fhe_hip_conv_to_normal", "fhe_hip_mul_relin_rescale_noalloc", "fhe_hip_set_tuning",
+    "fhe_hip_profile_get", "fhe_hip_batch_run", "fhe_hip_conv_to_normal", "fhe_hip_mul_relin_rescale_noalloc", "fhe_hip_set_tuning", "fhe_hip_debug_violations",
 ]
 OP_MUL_RELIN_RESCALE, OP_ROTATE, OP_ROTATE_MIXED, OP_ROTATE_NON_NTT = 1, 2, 3, 4
 TUNE_RELIN_GROUP = 1
@@ -293,6 +294,12 @@ class HipContext:
         _need(out=(out, batch * 2 * max(Li - 1, 0) * self.N), c0=(c0, batch * 2 * Li * self.N), c1=(c1, batch * 2 * Li * self.N))
         self._chk(self.lib.fhe_hip_mul_relin_rescale_noalloc(self.h, o, a, b, Li, batch))
         return out
+
+    def debug_violations(self):
+        """(count, first site, enabled): residue-range violations counted by a debug build since the last call."""
+        n, site, en = C.c_uint64(0), C.c_uint32(0), C.c_int(0)
+        self._chk(self.lib.fhe_hip_debug_violations(self.h, C.byref(n), C.byref(site), C.byref(en)))
+        return int(n.value), int(site.value), bool(en.value)
 
     def set_tuning(self, knob, value):
         self._chk(self.lib.fhe_hip_set_tuning(self.h, knob, value))

@@ -168,6 +168,13 @@ int fhe_hip_mul_relin_rescale_noalloc(fhe_hip_ctx *ctx, uint64_t *out, const uin
 #define FHE_HIP_TUNE_RELIN_GROUP 1
 int fhe_hip_set_tuning(fhe_hip_ctx *ctx, int knob, uint64_t value);
 
+/* Debug build support (reference analogue: the non-release -DCHECK_STRICTMOD range asserts, CMakeCompilers.txt:26).
+ * libfhe_hip_debug.so (make -C fhe_amd/csrc DEBUG=1) compiles residue-range checks into the kernels: < p on canonical
+ * outputs, < 4p / < 2p on lazy hand-offs and inputs.  Violations are counted on the device, never trapped.  This call
+ * returns how many were seen since the last call and the site of the first one (list in fhe_amd/csrc/modarith.h), and
+ * resets both; *enabled = 0 and a zero count in the ordinary build. */
+int fhe_hip_debug_violations(fhe_hip_ctx *ctx, uint64_t *count, uint32_t *first_site, int *enabled);
+
 /* Measurement support (no reference counterpart): when enabled every kernel launch is bracketed by
  * HIP events on the context's stream; stats are summed per kernel name. */
 int fhe_hip_profile_enable(fhe_hip_ctx *ctx, int on);

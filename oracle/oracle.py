@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "liboracle.so")
+# ORACLE_LIB selects another build of the same source (tools/run_sanitized_tests.sh: liboracle_san.so, ASan + UBSan)
+_LIB = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
 
 
 def build():

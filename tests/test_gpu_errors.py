@@ -112,3 +112,60 @@ def test_limb_count_and_galois_validation():
         g.apply_galois(ct[0, 0], 3, 2 * N + 1, batch=1)  # >= 2N
     with pytest.raises(fhe_amd.FheHipError):
         g.ntt_forward(ct[0, 0], [0, 1, 9])  # modulus index out of range
+
+
+def test_debug_build_counts_range_violations_and_sees_none_on_valid_inputs():
+    """libfhe_hip_debug.so (make -C fhe_amd/csrc DEBUG=1): residue-range checks inside the kernels.  Loaded through FHE_HIP_LIB in
+    a child process (the library path is read once per process): a full multiply+relin+rescale, a rotation and NTT round trips on
+    valid inputs raise no violation and still match the oracle; an inverse NTT fed values >= 2p is counted, not trapped."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "fhe_amd", "lib", "libfhe_hip_debug.so")
+    assert os.path.exists(lib), "run __graft_entry__.build() (make -C fhe_amd/csrc DEBUG=1)"
+    code = textwrap.dedent('''
+        import numpy as np, torch, fhe_amd
+        from oracle import oracle as orc
+        logN, L, K, Li = 12, 4, 4, 4
+        pr, ps = orc.gen_primes(logN, L + K)
+        o, g = orc.Oracle(logN, L, K, pr, ps), fhe_amd.HipContext(logN, L, K, pr, ps)
+        assert g.debug_violations()[2], "not a debug build"
+        rng = np.random.default_rng(5)
+        poly = lambda n=Li: np.stack([rng.integers(0, int(pr[i]), o.N, dtype=np.uint64) for i in range(n)])
+        dev = lambda a: torch.from_numpy(a.view(np.int64)).cuda()
+        host = lambda t: t.cpu().numpy().view(np.uint64)
+        x = poly(); idx = list(range(Li))
+        d = dev(x); g.ntt_forward(d, idx); g.ntt_backward(d, idx)
+        assert np.array_equal(host(d), x)
+        sx, ext = o.keygen_sk(seed=1)
+        beta, alpha = o.keygen_mult(sx, seed=2)
+        g.load_mult_key(dev(beta), dev(alpha))
+        c0 = np.stack([poly(), poly()]); c1 = np.stack([poly(), poly()])
+        wb, wa = o.mul_relin_rescale(c0[0], c0[1], c1[0], c1[1], beta, alpha)
+        out = torch.zeros((1, 2, Li - 1, o.N), dtype=torch.int64, device="cuda")
+        g.mul_relin_rescale(out, dev(c0[None]), dev(c1[None]), Li, batch=1)
+        h = host(out)
+        assert np.array_equal(h[0, 0], wb) and np.array_equal(h[0, 1], wa)
+        gal = o.rotation_galois(1)
+        rkb, rka = o.keygen_rot(sx, ext, gal, seed=3)
+        g.load_rot_key(gal, dev(rkb), dev(rka))
+        ct = dev(c0[None].copy()); g.rotate(gal, ct, Li, batch=1)
+        rb, ra = o.rotate(c0[0], c0[1], gal, rkb, rka)
+        assert np.array_equal(host(ct)[0, 0], rb) and np.array_equal(host(ct)[0, 1], ra)
+        n, site, en = g.debug_violations()
+        assert n == 0, (n, site)
+        bad = np.full((1, o.N), (1 << 64) - 5, np.uint64)   # >= 2p: outside the inverse NTT's input contract
+        db = dev(bad); g.ntt_backward(db, [0]); g.sync()
+        n, site, en = g.debug_violations()
+        assert n > 0 and site == 4, (n, site)
+        assert g.debug_violations()[0] == 0   # reading resets
+        print("debug build OK", n)
+    ''')
+    env = dict(os.environ, FHE_HIP_LIB=lib)
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "debug build OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_ordinary_build_reports_debug_checks_disabled():
+    o, g, pr, ps = _ctx()
+    assert g.debug_violations() == (0, 0, False)

@@ -542,3 +542,48 @@ def test_relinearisation_in_groups_of_output_limbs(logN, L, Li, group):
         g.set_tuning(fhe_amd.hip.TUNE_RELIN_GROUP, 0)
     with pytest.raises(fhe_amd.FheHipError):
         g.set_tuning(99, 1)
+
+
+# ---- full-size results pinned by mathematics, not only by the oracle ----
+@pytest.mark.parametrize("logN", [14, 15, 16])
+def test_full_size_forward_ntt_against_horner_in_python_integers(logN):
+    from horner import ntt_value_at, sample_positions
+    o, g = ctx_pair(logN, 2, 1)
+    rng = np.random.default_rng(2000 + logN)
+    idx = [0, 2, 1]
+    x = rand_poly(o, idx, 2100 + logN)
+    d = dev(x)
+    g.ntt_forward(d, idx)
+    got = host(d)
+    for row, m in enumerate(idx):
+        p, psi = int(o.primes[m]), int(o.psi[m])
+        coeffs = [int(v) for v in x[row]]
+        for pos in sample_positions(logN, rng, 6):
+            assert int(got[row][pos]) == ntt_value_at(coeffs, pos, logN, psi, p), (logN, m, pos)
+
+
+def test_full_size_relinearisation_against_python_integers():
+    """N = 2^16: sampled output coefficients of fhe_hip_relin_only recomputed from Horner evaluations of the digit
+    polynomials and the key entries (no oracle in the loop except for the digits, which are pinned by evaluation too)."""
+    from horner import ntt_value_at
+    logN, L, K, Li = 16, 3, 1, 3
+    o, g = ctx_pair(logN, L, K)
+    rng = np.random.default_rng(78)
+    poly = lambda: np.stack([rng.integers(0, int(o.primes[i]), o.N, dtype=np.uint64) for i in range(Li)])  # noqa: E731
+    ct3 = np.stack([poly(), poly(), poly()])
+    beta, alpha = np.stack([poly() for _ in range(L)]), np.stack([poly() for _ in range(L)])
+    g.load_mult_key(dev(beta), dev(alpha))
+    out = torch.zeros((1, 2, Li, o.N), dtype=torch.int64, device="cuda")
+    g.relin_only(out, dev(ct3[None]), Li, batch=1)
+    got = host(out)[0]
+    dd = dev(ct3[2].copy())
+    g.ntt_backward(dd, list(range(Li)))
+    digits = host(dd)
+    dig = [[int(v) for v in digits[j]] for j in range(Li)]
+    for j in range(Li):
+        assert ntt_value_at(dig[j], 777, logN, int(o.psi[j]), int(o.primes[j])) == int(ct3[2][j][777])
+    for i, d in ((0, 5), (2, 65535), (1, 32768)):
+        pi, si = int(o.primes[i]), int(o.psi[i])
+        vals = [ntt_value_at(dig[j], d, logN, si, pi) for j in range(Li)]
+        assert int(got[0][i][d]) == (sum(vals[j] * int(beta[j][i][d]) for j in range(Li)) + int(ct3[0][i][d])) % pi
+        assert int(got[1][i][d]) == (sum(vals[j] * int(alpha[j][i][d]) for j in range(Li)) + int(ct3[1][i][d])) % pi

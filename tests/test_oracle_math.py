@@ -382,3 +382,49 @@ def test_rotate_non_ntt_is_the_literal_composition_of_the_reference_steps():
     assert np.array_equal(nb, bx) and np.array_equal(na, ax)
     with pytest.raises(ValueError):
         o.rotate_non_ntt(bx[:1], ax[:1], g, rkb, rka)  # Li <= 1: mod_up throws (base_converter.cpp:284-285)
+
+
+# ---- full-size pins by mathematics (N = 2^14 .. 2^16): sampled outputs recomputed by Horner's rule in Python integers ----
+from horner import horner_eval, ntt_value_at, sample_positions  # noqa: E402
+
+
+@pytest.mark.parametrize("logN", [14, 15, 16])
+def test_full_size_forward_ntt_at_sampled_points(logN):
+    """Above logN = 8 the O(N^2) schoolbook check is out of reach; one output is N mulmods: X[d] = x(psi^(2 brv(d)+1))."""
+    o = orc.Oracle(logN, 2, 1)
+    rng = np.random.default_rng(1000 + logN)
+    for idx in (0, 2):  # a normal and the special prime
+        p, psi = int(o.primes[idx]), int(o.psi[idx])
+        x = rng.integers(0, p, o.N, dtype=np.uint64)
+        got = o.ntt_forward(x.copy()[None], [idx])[0]
+        coeffs = [int(v) for v in x]
+        for d in sample_positions(logN, rng):
+            assert int(got[d]) == ntt_value_at(coeffs, d, logN, psi, p), (logN, idx, d)
+        # and the inverse: INTT(got) must be x (forward at sampled points + exact round trip pin backward too)
+        assert np.array_equal(o.ntt_backward(got.copy()[None], [idx])[0], x)
+
+
+def test_full_size_relinearisation_at_sampled_coefficients():
+    """N = 2^16, Li = 3: one output coefficient of Mul::reLinearize (reference src/evaluator.cpp:663-691) is
+    sum_j NTT_i(INTT_j(d2_j))[d] * beta_j[i][d] + d0[i][d]; the digit polynomials INTT_j(d2_j) are pinned by evaluating them
+    back at sampled points, the sum is recomputed in Python integers."""
+    logN, L, K, Li = 16, 3, 1, 3
+    o = orc.Oracle(logN, L, K)
+    rng = np.random.default_rng(77)
+    poly = lambda: np.stack([rng.integers(0, int(o.primes[i]), o.N, dtype=np.uint64) for i in range(Li)])  # noqa: E731
+    d0, d1, d2 = poly(), poly(), poly()
+    beta, alpha = np.stack([poly() for _ in range(L)]), np.stack([poly() for _ in range(L)])
+    out0, out1 = o.relinearize(d0, d1, d2, beta, alpha)
+    digits = o.ntt_backward(d2.copy(), range(Li))  # c_j = INTT_j(d2_j), coefficients below q_j
+    dig = [[int(v) for v in digits[j]] for j in range(Li)]
+    for j in range(Li):  # pin the digits: their forward NTT under q_j at sampled points is d2_j
+        pj, sj = int(o.primes[j]), int(o.psi[j])
+        for d in (0, 12345, o.N - 1):
+            assert ntt_value_at(dig[j], d, logN, sj, pj) == int(d2[j][d])
+    for i, d in ((0, 0), (1, 40000), (2, o.N - 1), (1, 1)):
+        pi, si = int(o.primes[i]), int(o.psi[i])
+        vals = [ntt_value_at(dig[j], d, logN, si, pi) for j in range(Li)]  # NTT_i of the residues of another prime, j == i included
+        assert vals[i] == int(d2[i][d])
+        w0 = (sum(vals[j] * int(beta[j][i][d]) for j in range(Li)) + int(d0[i][d])) % pi
+        w1 = (sum(vals[j] * int(alpha[j][i][d]) for j in range(Li)) + int(d1[i][d])) % pi
+        assert int(out0[i][d]) == w0 and int(out1[i][d]) == w1, (i, d)
