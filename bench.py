@@ -293,8 +293,8 @@ class Setup:
             self.rkb, self.rka = key(L + K, N), key(L + K, N)
             self.galois = 3
             ctx.load_rot_key(self.galois, self.rkb, self.rka)
-            self.work = self.ct.clone()
-            self.step = lambda: ctx.rotate(self.galois, self.work, Li, batch=B)
+            self.work = torch.empty_like(self.ct)
+            self.step = lambda: ctx.rotate_to(self.galois, self.work, self.ct, Li, batch=B)  # out of place: B ciphertexts in, B out
             self.metric, self.unit = "rotation-keyswitch/sec at N=2^%d, Li=K=%d" % (logN, Li), "ops/s"
         elif workload in GENERIC:
             galois = 3

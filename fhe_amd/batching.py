@@ -156,9 +156,9 @@ class ShardedEvaluator:
         N = self.N
 
         def compute(local, n):
-            work = local[0].contiguous().clone()
+            work = torch.empty((n, 2, Li, N), dtype=torch.int64, device=self.batch.device)
             if n:
-                self.ctx.rotate(galois, work, Li, batch=n)
+                self.ctx.rotate_to(galois, work, local[0].contiguous(), Li, batch=n)
             return work
 
         return self.batch.run(compute, [ct], n_items, [(2, Li, N)], (2, Li, N), chunk)

@@ -234,6 +234,7 @@ struct NttPlan {
   const u32 *perm = nullptr;          // inverse only: gather the source through a galois index table
   const u32 *epi_add_perm = nullptr;  // gather the epilogue addend through a galois index table
   const u64 *pre_a = nullptr, *pre_k = nullptr;  // inverse, 8-element row pass only: element = src + pre_k * pre_a (NttArgs::pre_a)
+  const u64 *epi_key0 = nullptr, *epi_key1 = nullptr; u64 epi_half = 0;  // epi == 4 (NttArgs::epi_key0)
 };
 
 template <bool SP, bool INV>
@@ -269,9 +270,11 @@ int launch_rows(fhe_hip_ctx *c, const NttArgs &a, u32 nl, u32 batch) {
     if (a.epi == 1) { LAUNCH(c, "ntt_fwd_rows_rescale", (ntt_rows8_fwd_kernel<SP, 1>), grid, block, a); return FHE_HIP_OK; }
     if (a.epi == 2) { LAUNCH(c, "ntt_fwd_rows_moddown", (ntt_rows8_fwd_kernel<SP, 2>), grid, block, a); return FHE_HIP_OK; }
     if (a.epi == 3) { LAUNCH(c, "ntt_fwd_rows_encrypt", (ntt_rows8_fwd_kernel<SP, 3>), grid, block, a); return FHE_HIP_OK; }
+    if (a.epi == 4) { LAUNCH(c, "ntt_fwd_rows_rotdown", (ntt_rows8_fwd_kernel<SP, 4>), grid, block, a); return FHE_HIP_OK; }
     LAUNCH(c, "ntt_fwd_rows", (ntt_rows8_fwd_kernel<SP, 0>), grid, block, a);
   } else {
-    LAUNCH(c, "ntt_inv_rows", (ntt_rows8_inv_kernel<SP>), grid, block, a);
+    if (a.pre_a) LAUNCH(c, "ntt_inv_rows_decrypt", (ntt_rows8_inv_kernel<SP, true>), grid, block, a);
+    else LAUNCH(c, "ntt_inv_rows", (ntt_rows8_inv_kernel<SP, false>), grid, block, a);
   }
   return FHE_HIP_OK;
 }
@@ -282,16 +285,19 @@ int ntt_run_sp(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
   NttArgs a;
   a.tw = inverse ? c->d_tw_inv : c->d_tw_fwd;
   a.primes = c->d_primes; a.midx = p.midx; a.mdiv = p.mdiv; a.mper = p.mper;
+  auto inv32 = [](u32 d) { return (u32)(((1ull << 32) + d - 1) / (d ? d : 1)); };  // ceil(2^32 / d); unused for d == 1
+  a.mdiv_inv = inv32(p.mdiv); a.mper_inv = inv32(p.mper);
   a.logN = c->logN; a.logR = c->logR; a.l0 = p.l0; a.skip_diag = p.skip_diag;
   a.dst = p.dst; a.dst_bstride = p.dst_bstride;
   a.epi = inverse ? 0 : p.epi; a.epi_src = p.epi_src; a.epi_c = p.epi_c; a.epi_add = p.epi_add; a.epi_out = p.epi_out;
   a.epi_src_bstride = p.epi_src_bstride; a.epi_add_bstride = p.epi_add_bstride; a.epi_out_bstride = p.epi_out_bstride;
+  a.epi_key0 = p.epi_key0; a.epi_key1 = p.epi_key1; a.epi_half = p.epi_half;
   a.perm = nullptr; a.pre_a = nullptr; a.pre_k = nullptr; a.epi_add_perm = p.epi_add_perm; a.inv_scale = inverse ? p.inv_scale : nullptr;
   // first pass reads the (possibly broadcast) source, second pass runs in place on dst
   NttArgs first = a, second = a;
-  first.src = p.src; first.src_bstride = p.src_bstride; first.smod = p.smod;
+  first.src = p.src; first.src_bstride = p.src_bstride; first.smod = p.smod; first.smod_inv = inv32(p.smod);
   if (inverse) { first.perm = p.perm; first.pre_a = p.pre_a; first.pre_k = p.pre_k; }
-  second.src = p.dst; second.src_bstride = p.dst_bstride; second.smod = p.nl;
+  second.src = p.dst; second.src_bstride = p.dst_bstride; second.smod = p.nl; second.smod_inv = inv32(p.nl);
   if (!inverse) {
     TRY((launch_cols<SP, false>(c, first, p.nl, p.batch)));
     if (!p.cols_only) TRY((launch_rows<SP, false>(c, second, p.nl, p.batch)));
@@ -304,7 +310,9 @@ int ntt_run_sp(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
 
 int ntt_run(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
   // grid.y / grid.z limits: split large limb counts over several launches
-  if (p.nl > 65535 || p.batch > 65535) FAIL(c, FHE_HIP_ERR_RANGE, "too many limbs in one NTT launch");
+  if (p.skip_diag && p.skip_diag != p.mdiv) FAIL(c, FHE_HIP_ERR_ARG, "internal: skip_diag must equal mdiv");
+  if (p.nl + p.l0 > 65535 || p.batch > 65535 || p.mdiv > 65535 || p.mper > 65535 || p.smod > 65535)
+    FAIL(c, FHE_HIP_ERR_RANGE, "too many limbs in one NTT launch");  // also the range limb_div is exact on
   return c->sp ? ntt_run_sp<true>(c, p, inverse) : ntt_run_sp<false>(c, p, inverse);
 }
 
@@ -508,93 +516,93 @@ int get_galois_perm(fhe_hip_ctx *c, u64 galois, u32 **perm) {
   return FHE_HIP_OK;
 }
 
-// rotate_slots_inplace + apply_rotation_key (evaluator.cpp:299-311, 343-399); ct = [b][2][Li][N] in place
-// non_ntt = Evaluator::Impl::rotate_slots_inplace_non_ntt + apply_rotation_key_non_ntt (src/evaluator.cpp:327-339, 520-574): ct in the
-// power basis; reproduced literally, including approximated_mod_down adding its NTT-domain correction to power-basis limbs.
-int dev_rotate(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch, bool non_ntt = false) {
-  const u64 N = c->N; const u32 K = c->K, nl = Li + K;
+// rotate_slots_inplace + apply_rotation_key (evaluator.cpp:299-311, 343-399), out of place: in, out = [b][2][Li][N], out != in.
+// Nine launches.  galois() of both halves is applied inside the loads of its readers (inverse row pass of ax, the mod-down
+// tail), so no permuted copy is ever written; the key product of the normal limbs is formed in that tail as well; the two
+// halves of the key-switched polynomial travel as 2*batch entries, one launch per step.  E = [b][2][K][N] holds the special
+// limbs only (the normal limbs of the extended polynomial are galois(ax) itself: NTT(INTT(x)) = x).
+int dev_rotate_to(fhe_hip_ctx *c, u64 galois, u64 *out, const u64 *in, u32 Li, u32 batch) {
+  const u64 N = c->N; const u32 K = c->K;
   auto it = c->rot_keys.find(galois);
   if (it == c->rot_keys.end()) FAIL(c, FHE_HIP_ERR_NOKEY, "rotation key not loaded for this galois element");
   u32 *perm = nullptr;
-  const bool identity = (galois == 1);
+  if (galois != 1) TRY(get_galois_perm(c, galois, &perm));
+  TRY(ensure_ws(c, 0, (size_t)batch * Li * N * 8));        // base-conversion digits of galois(ax), power basis
+  TRY(ensure_ws(c, 4, (size_t)batch * 2 * K * N * 8));     // E
+  TRY(ensure_ws(c, 2, (size_t)batch * 2 * Li * N * 8));    // conversions back to the normal basis, both halves
+  u64 *pw = (u64 *)c->ws[0], *E = (u64 *)c->ws[4], *conv = (u64 *)c->ws[2];
+  // power basis of galois(ax) (d[1]->backward(), :360), scaled so that it comes out as the mod-up digits [ax * hat_inv]_q
+  NttPlan pi{in + (size_t)Li * N, pw, c->d_iota, 1, Li, Li, Li, batch, (u64)2 * Li * N, (u64)Li * N};
+  pi.perm = perm;
+  pi.inv_scale = c->d_modup_scale_m + (size_t)(Li - 2) * c->M;
+  TRY(ntt_run(c, pi, true));
+  TRY(dev_conv_to_special(c, E, 2 * K, 0, pw, Li, Li, batch, true));  // special limbs -> E[b][0]
+  // forward NTT of the K special limbs (:363-366): column pass; the row pass, both key products (:373-384) and the row pass of
+  // the two inverse NTTs (:386-392) run fused in rot_special_rows8_kernel, which leaves half 1 in E[b][1]
+  NttPlan pf{E, E, c->d_iota + c->L, 1, K, K, K, batch, (u64)2 * K * N, (u64)2 * K * N};
+  pf.cols_only = true;
+  TRY(ntt_run(c, pf, false));
+  RotSpArgs ra;
+  ra.e0 = E; ra.e1 = E + (size_t)K * N; ra.estride = (u64)2 * K * N; ra.beta_m = it->second.beta_m; ra.alpha_m = it->second.alpha_m;
+  ra.tw_fwd = c->d_tw_fwd; ra.tw_inv = c->d_tw_inv; ra.primes = c->d_primes;
+  ra.first_mod = c->L; ra.first_limb = 0; ra.logN = c->logN; ra.logR = c->logR;
+  const u32 R = 1u << c->logR, rows = R < 8 ? R : 8;
+  LAUNCH_SP(c, "rot_special_rows", rot_special_rows8_kernel, dim3(R / rows, K, batch), dim3(32 * rows), ra);
+  // from here on the two halves are 2*batch entries of K special limbs: column pass of their inverse NTTs (output = mod-down digits)
+  NttPlan pc{E, E, c->d_iota + c->L, 1, K, K, K, 2 * batch, (u64)K * N, (u64)K * N};
+  pc.cols_only = true; pc.inv_scale = c->d_moddown_scale_m;
+  TRY(ntt_run(c, pc, true));
+  // approximated_mod_down (base_converter.cpp:205-242): conversion to the normal basis, forward NTT, and the tail fused with
+  // the normal-limb key product and "+ galois(bx)" in the row pass (NttArgs::epi == 4), written straight into out
+  TRY(dev_conv_to_normal(c, conv, Li, E, K, 0, 2 * batch, true));
+  NttPlan p{conv, conv, c->d_iota, 1, Li, Li, Li, 2 * batch, (u64)Li * N, (u64)Li * N};
+  p.epi = 4; p.epi_src = in; p.epi_src_bstride = (u64)2 * Li * N; p.epi_half = (u64)Li * N; p.epi_c = c->d_Pinv_qj_m;
+  p.epi_key0 = it->second.beta_m; p.epi_key1 = it->second.alpha_m; p.epi_add_perm = perm;
+  p.epi_out = out; p.epi_out_bstride = (u64)Li * N;
+  TRY(ntt_run(c, p, false));
+  return FHE_HIP_OK;
+}
+
+// Evaluator::Impl::rotate_slots_inplace_non_ntt + apply_rotation_key_non_ntt (src/evaluator.cpp:327-339, 520-574): ct in the power
+// basis, in place; reproduced literally, including approximated_mod_down adding its NTT-domain correction to power-basis limbs.
+int dev_rotate_non_ntt(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch) {
+  const u64 N = c->N; const u32 K = c->K, nl = Li + K;
+  auto it = c->rot_keys.find(galois);
+  if (it == c->rot_keys.end()) FAIL(c, FHE_HIP_ERR_NOKEY, "rotation key not loaded for this galois element");
   const size_t ctb = (size_t)batch * 2 * Li * N * 8, extb = (size_t)batch * nl * N * 8;
   TRY(ensure_ws(c, 3, ctb));       // g = galois(ct): [b][2][Li][N]
   TRY(ensure_ws(c, 4, extb));      // ext / e0
   TRY(ensure_ws(c, 5, extb));      // e1
-  TRY(ensure_ws(c, 0, (size_t)batch * Li * N * 8));  // power-basis copy of ax_g
-  u64 *g = (u64 *)c->ws[3], *e0 = (u64 *)c->ws[4], *e1 = (u64 *)c->ws[5], *pw = (u64 *)c->ws[0];
-  // NTT path with a real permutation: only galois(bx) is materialised (it is the in-place addend of half 0); galois(ax) is
-  // applied inside the loads of its two readers (inverse row pass, key product).
-  const bool fused = !identity && !non_ntt;
-  const u64 g_bstride = fused ? (u64)Li * N : (u64)2 * Li * N;
-  if (identity) {
+  u64 *g = (u64 *)c->ws[3], *e0 = (u64 *)c->ws[4], *e1 = (u64 *)c->ws[5];
+  if (galois == 1) {
     HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(g, ct, ctb, hipMemcpyDeviceToDevice, c->stream)));
-  } else if (non_ntt) {
+  } else {
     LAUNCH(c, "galois_coeff", galois_coeff_kernel, dim3((unsigned)(N / PW_THREADS), 2 * Li, batch), dim3(PW_THREADS), g, (const u64 *)ct,
            (const PrimeC *)c->d_primes, c->logN, galois_inverse(galois, c->N), Li);
-  } else {
-    TRY(get_galois_perm(c, galois, &perm));
-    LAUNCH(c, "galois_gather", galois_gather_kernel, dim3((unsigned)(N / PW_THREADS), Li, batch), dim3(PW_THREADS), g, (const u64 *)ct,
-           (const u32 *)perm, N, (u64)2 * Li * N, g_bstride);
   }
-  const u64 *axg = fused ? ct + (size_t)Li * N : g + (size_t)Li * N;  // galois(ax), through perm when fused
-  const bool fused_sp = !non_ntt;  // NTT path: special limbs go through rot_special_rows8_kernel
-  if (non_ntt) {
-    // ax_g is already in the power basis (:537): mod up, then forward NTT of all Li+K limbs (:539-542)
-    TRY(dev_conv_to_special(c, e0, nl, Li, g + (size_t)Li * N, 2 * Li, Li, batch));
-    for (u32 b = 0; b < batch; ++b)
-      HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(e0 + (size_t)b * nl * N, g + ((size_t)b * 2 + 1) * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream)));
-    NttPlan pf{e0, e0, c->d_rotmap + (size_t)Li * c->M, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
-    TRY(ntt_run(c, pf, false));
-  } else {
-    // power basis of ax_g (d[1]->backward(), :360)
-    NttPlan pi{axg, pw, c->d_iota, 1, Li, Li, Li, batch, (u64)2 * Li * N, (u64)Li * N};
-    pi.perm = fused ? perm : nullptr;
-    pi.inv_scale = c->d_modup_scale_m + (size_t)(Li - 2) * c->M;  // pw = base-conversion digits [ax * hat_inv]_q, not ax itself
-    TRY(ntt_run(c, pi, true));
-    // mod up: special limbs from the power basis; normal limbs of the NTT-domain result are ax_g itself
-    // (NTT(INTT(x)) = x for canonical x, so the Li forward NTTs of :363-366 are not recomputed)
-    TRY(dev_conv_to_special(c, e0, nl, Li, pw, Li, Li, batch, true));
-    // forward NTT of the K special limbs: column pass here; the row pass, both key products and the row pass of the two
-    // inverse NTTs (:363-392 for cm >= Li) run fused in rot_special_rows8_kernel
-    NttPlan pf{e0 + (size_t)Li * N, e0 + (size_t)Li * N, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
-    pf.cols_only = true;
-    TRY(ntt_run(c, pf, false));
-  }
+  // ax_g is already in the power basis (:537): mod up, then forward NTT of all Li+K limbs (:539-542)
+  TRY(dev_conv_to_special(c, e0, nl, Li, g + (size_t)Li * N, 2 * Li, Li, batch));
+  for (u32 b = 0; b < batch; ++b)
+    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(e0 + (size_t)b * nl * N, g + ((size_t)b * 2 + 1) * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream)));
   const u32 *rotmap = c->d_rotmap + (size_t)Li * c->M;
-  if (fused_sp) {
-    RotSpArgs ra;
-    ra.e0 = e0; ra.e1 = e1; ra.beta_m = it->second.beta_m; ra.alpha_m = it->second.alpha_m;
-    ra.tw_fwd = c->d_tw_fwd; ra.tw_inv = c->d_tw_inv; ra.primes = c->d_primes;
-    ra.first_mod = c->L; ra.first_limb = Li; ra.nl = nl; ra.logN = c->logN; ra.logR = c->logR;
-    const u32 R = 1u << c->logR, rows = R < 8 ? R : 8;
-    LAUNCH_SP(c, "rot_special_rows", rot_special_rows8_kernel, dim3(R / rows, K, batch), dim3(32 * rows), ra);
-    // key product of the Li normal limbs (read through the galois table when fused)
-    LAUNCH_SP(c, "rot_keymul", rot_keymul_kernel, pw_grid(c, Li, batch), dim3(PW_THREADS), e0, e1, (const u64 *)e0, (const u64 *)it->second.beta_m,
-              (const u64 *)it->second.alpha_m, (const PrimeC *)c->d_primes, rotmap, nl, N, axg, (u64)2 * Li * N, Li, (const u32 *)(fused ? perm : nullptr));
-    for (int h = 0; h < 2; ++h) {  // column pass of the inverse NTTs of the special limbs (:386-392)
-      u64 *e = (h == 0 ? e0 : e1) + (size_t)Li * N;
-      NttPlan pc{e, e, c->d_iota + c->L, 1, K, K, K, batch, (u64)nl * N, (u64)nl * N};
-      pc.cols_only = true; pc.inv_scale = c->d_moddown_scale_m;  // special limbs come out as mod-down digits
-      TRY(ntt_run(c, pc, true));
-    }
-  } else {  // power-basis variant: key product over all Li+K limbs, then every limb back to the power basis (:544-567)
-    LAUNCH_SP(c, "rot_keymul", rot_keymul_kernel, pw_grid(c, nl, batch), dim3(PW_THREADS), e0, e1, (const u64 *)e0, (const u64 *)it->second.beta_m,
-              (const u64 *)it->second.alpha_m, (const PrimeC *)c->d_primes, rotmap, nl, N, (const u64 *)nullptr, (u64)2 * Li * N, Li, (const u32 *)nullptr);
-    NttPlan p0{e0, e0, c->d_rotmap + (size_t)Li * c->M, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
-    TRY(ntt_run(c, p0, true));
-    NttPlan p1{e1, e1, c->d_rotmap + (size_t)Li * c->M, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
-    TRY(ntt_run(c, p1, true));
-  }
-  // mod down both halves straight into ct (strided [b][2][Li][N]); rop[0] += galois(bx) read from g (:394-398)
+  NttPlan pf{e0, e0, rotmap, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
+  TRY(ntt_run(c, pf, false));
+  // key product over all Li+K limbs, then every limb back to the power basis (:544-567)
+  LAUNCH_SP(c, "rot_keymul", rot_keymul_kernel, pw_grid(c, nl, batch), dim3(PW_THREADS), e0, e1, (const u64 *)e0, (const u64 *)it->second.beta_m,
+            (const u64 *)it->second.alpha_m, (const PrimeC *)c->d_primes, rotmap, nl, N);
+  NttPlan p0{e0, e0, rotmap, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
+  TRY(ntt_run(c, p0, true));
+  NttPlan p1{e1, e1, rotmap, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
+  TRY(ntt_run(c, p1, true));
+  // mod down both halves straight into ct (strided [b][2][Li][N]); rop[0] += galois(bx) read from g (:568-572)
   TRY(ensure_ws(c, 2, (size_t)batch * Li * N * 8));
   u64 *conv = (u64 *)c->ws[2];
   for (int h = 0; h < 2; ++h) {
     const u64 *op = h == 0 ? e0 : e1;
-    TRY(dev_conv_to_normal(c, conv, Li, op, nl, Li, batch, !non_ntt));
+    TRY(dev_conv_to_normal(c, conv, Li, op, nl, Li, batch, false));
     NttPlan p{conv, conv, c->d_iota, 1, Li, Li, Li, batch, (u64)Li * N, (u64)Li * N};
     p.epi = 2; p.epi_src = op; p.epi_src_bstride = (u64)nl * N; p.epi_c = c->d_Pinv_qj_m;
-    p.epi_add = h == 0 ? g : nullptr; p.epi_add_bstride = g_bstride;
+    p.epi_add = h == 0 ? g : nullptr; p.epi_add_bstride = (u64)2 * Li * N;
     p.epi_out = ct + (size_t)h * Li * N; p.epi_out_bstride = (u64)2 * Li * N;
     TRY(ntt_run(c, p, false));
   }
@@ -1094,27 +1102,74 @@ int fhe_hip_set_tuning(fhe_hip_ctx *c, int knob, uint64_t value) {
   FAIL(c, FHE_HIP_ERR_ARG, "unknown tuning knob");
 }
 
-static int rotate_api(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind, bool non_ntt) {
+static int rotate_check(fhe_hip_ctx *c, uint64_t galois, uint32_t Li) {
+  if (!(galois & 1) || galois >= 2 * c->N) FAIL(c, FHE_HIP_ERR_ARG, "galois must be odd and < 2N");
+  TRY(check_li(c, Li, 2));  // Li <= 1: mod_up throws (base_converter.cpp:284-285)
+  if (c->K < 1) FAIL(c, FHE_HIP_ERR_RANGE, "rotation needs special primes");
+  return FHE_HIP_OK;
+}
+
+int fhe_hip_rotate_to(fhe_hip_ctx *c, uint64_t galois, uint64_t *out, const uint64_t *in, uint32_t Li, size_t batch, int mem_kind) {
+  try {
+  TRY(check_ctx(c));
+  if (!out || !in) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (out == in) FAIL(c, FHE_HIP_ERR_ARG, "fhe_hip_rotate_to is out of place: out must differ from in (fhe_hip_rotate works in place)");
+  const size_t bytes = batch * 2 * Li * c->N * 8;
+  if (galois == 0) {  // no rotation (evaluator.cpp:303-304): the result is the input
+    if (batch == 0) return FHE_HIP_OK;
+    if (mem_kind == FHE_HIP_MEM_DEVICE) HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, c->stream)));
+    else std::memmove(out, in, bytes);
+    return FHE_HIP_OK;
+  }
+  TRY(rotate_check(c, galois, Li));
+  if (batch == 0) return FHE_HIP_OK;
+  Staged st(c, mem_kind);
+  const u64 *din = nullptr; u64 *dout = nullptr;
+  TRY(st.in(in, bytes, &din));
+  TRY(st.out(out, bytes, &dout, false));
+  TRY(dev_rotate_to(c, galois, dout, din, Li, (u32)batch));
+  return st.finish();
+  } catch (...) { return abi_exception(); }
+}
+
+int fhe_hip_rotate(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind) {
   try {
   TRY(check_ctx(c));
   if (!ct) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   if (galois == 0) return FHE_HIP_OK;  // evaluator.cpp:303-304
-  if (!(galois & 1) || galois >= 2 * c->N) FAIL(c, FHE_HIP_ERR_ARG, "galois must be odd and < 2N");
-  TRY(check_li(c, Li, 2));  // Li <= 1: mod_up throws (base_converter.cpp:284-285)
-  if (c->K < 1) FAIL(c, FHE_HIP_ERR_RANGE, "rotation needs special primes");
+  TRY(rotate_check(c, galois, Li));
+  if (batch == 0) return FHE_HIP_OK;
+  const size_t bytes = batch * 2 * Li * c->N * 8;
+  if (mem_kind == FHE_HIP_MEM_DEVICE) {
+    // the pipeline reads its input through the galois table until its last kernel: the result is formed beside the
+    // ciphertexts and copied over them (callers that can give a separate output use fhe_hip_rotate_to and save the copy)
+    TRY(ensure_ws(c, 3, bytes));
+    TRY(dev_rotate_to(c, galois, (u64 *)c->ws[3], (const u64 *)ct, Li, (u32)batch));
+    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(ct, c->ws[3], bytes, hipMemcpyDeviceToDevice, c->stream)));
+    return FHE_HIP_OK;
+  }
+  Staged st(c, mem_kind);  // host memory: staged in and out through two different device buffers anyway
+  const u64 *din = nullptr; u64 *dout = nullptr;
+  TRY(st.in(ct, bytes, &din));
+  TRY(st.out(ct, bytes, &dout, false));
+  TRY(dev_rotate_to(c, galois, dout, din, Li, (u32)batch));
+  return st.finish();
+  } catch (...) { return abi_exception(); }
+}
+
+int fhe_hip_rotate_non_ntt(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind) {
+  try {
+  TRY(check_ctx(c));
+  if (!ct) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (galois == 0) return FHE_HIP_OK;  // evaluator.cpp:331-332
+  TRY(rotate_check(c, galois, Li));
   if (batch == 0) return FHE_HIP_OK;
   Staged st(c, mem_kind);
   u64 *d = nullptr;
   TRY(st.out(ct, batch * 2 * Li * c->N * 8, &d, true));
-  TRY(dev_rotate(c, galois, d, Li, (u32)batch, non_ntt));
+  TRY(dev_rotate_non_ntt(c, galois, d, Li, (u32)batch));
   return st.finish();
   } catch (...) { return abi_exception(); }
-}
-int fhe_hip_rotate(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind) {
-  return rotate_api(c, galois, ct, Li, batch, mem_kind, false);
-}
-int fhe_hip_rotate_non_ntt(fhe_hip_ctx *c, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind) {
-  return rotate_api(c, galois, ct, Li, batch, mem_kind, true);
 }
 
 // Single-process multi-GPU mode: contiguous split of the batch over the contexts (the rule of fhe_amd/batching.py:shard_bounds:
@@ -1156,7 +1211,7 @@ struct BatchPipe {
   }
 };
 
-int batch_ensure(fhe_hip_ctx *c, size_t in_bytes, size_t out_bytes, bool two_inputs) {
+int batch_ensure(fhe_hip_ctx *c, size_t in_bytes, size_t out_bytes, bool two_inputs, bool one_input) {
   if (!c->br_up[0]) {
     for (int l = 0; l < BR_LANES; ++l) {
       HIPCHK(c, hipStreamCreateWithFlags(&c->br_up[l], hipStreamNonBlocking));
@@ -1166,7 +1221,7 @@ int batch_ensure(fhe_hip_ctx *c, size_t in_bytes, size_t out_bytes, bool two_inp
     for (int k = 0; k < BR_SLOTS; ++k) HIPCHK(c, hipEventCreateWithFlags(&c->br_ev_done[k], hipEventDisableTiming));
   }
   for (int k = 0; k < BR_SLOTS; ++k) {
-    const size_t want[3] = {two_inputs ? in_bytes : 0, two_inputs ? in_bytes : 0, out_bytes};
+    const size_t want[3] = {(two_inputs || one_input) ? in_bytes : 0, two_inputs ? in_bytes : 0, out_bytes};
     for (int j = 0; j < 3; ++j) {
       if (c->br_bytes[k][j] >= want[j]) continue;
       if (c->br_buf[k][j]) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->br_buf[k][j])); c->br_buf[k][j] = nullptr; c->br_bytes[k][j] = 0; }
@@ -1207,7 +1262,8 @@ int fhe_hip_batch_run(fhe_hip_ctx *const *ctxs, uint32_t n_ctx, int op, uint64_t
     if (hi == lo) return;
     if ((rc[g] = check_ctx(c)) != FHE_HIP_OK) return;
     const size_t per_chunk = std::min(BR_CHUNK, hi - lo), nchunks = (hi - lo + BR_CHUNK - 1) / BR_CHUNK;
-    if ((rc[g] = batch_ensure(c, per_chunk * in_ct * 8, per_chunk * out_ct * 8, mul)) != FHE_HIP_OK) return;
+    const bool oop = mul || op == FHE_HIP_OP_ROTATE;  // separate input slot(s): the rotation runs out of place on the device
+    if ((rc[g] = batch_ensure(c, per_chunk * in_ct * 8, per_chunk * out_ct * 8, mul, op == FHE_HIP_OP_ROTATE)) != FHE_HIP_OK) return;
     BatchPipe pipe;
     auto chunk_n = [&](size_t k) { return std::min(BR_CHUNK, hi - lo - k * BR_CHUNK); };
     auto hip_fail = [&](const char *what, hipError_t e) { pipe.fail(FHE_HIP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
@@ -1224,7 +1280,8 @@ int fhe_hip_batch_run(fhe_hip_ctx *const *ctxs, uint32_t n_ctx, int op, uint64_t
           if ((e = hipMemcpyAsync(c->br_buf[s][lane], src, n * in_ct * 8, hipMemcpyHostToDevice, c->br_up[lane])) != hipSuccess) return hip_fail("hipMemcpyAsync (upload)", e);
         } else {
           const size_t words = n * out_ct, half = words / 2, w0 = lane == 0 ? 0 : half, wn = lane == 0 ? half : words - half;
-          if ((e = hipMemcpyAsync((uint64_t *)c->br_buf[s][2] + w0, out + at * out_ct + w0, wn * 8, hipMemcpyHostToDevice, c->br_up[lane])) != hipSuccess) return hip_fail("hipMemcpyAsync (upload)", e);
+          uint64_t *dst = (uint64_t *)c->br_buf[s][oop ? 0 : 2];  // in-place ops are uploaded into the slot they are computed and downloaded from
+          if ((e = hipMemcpyAsync(dst + w0, out + at * out_ct + w0, wn * 8, hipMemcpyHostToDevice, c->br_up[lane])) != hipSuccess) return hip_fail("hipMemcpyAsync (upload)", e);
         }
         if ((e = hipEventRecord(c->br_ev_up[lane][s], c->br_up[lane])) != hipSuccess) return hip_fail("hipEventRecord", e);
         pipe.advance(pipe.up_done[lane]);
@@ -1258,7 +1315,7 @@ int fhe_hip_batch_run(fhe_hip_ctx *const *ctxs, uint32_t n_ctx, int op, uint64_t
       uint64_t *d = (uint64_t *)c->br_buf[s][2];
       int r;
       if (mul) r = fhe_hip_mul_relin_rescale(c, d, (const uint64_t *)c->br_buf[s][0], (const uint64_t *)c->br_buf[s][1], Li, n, FHE_HIP_MEM_DEVICE);
-      else if (op == FHE_HIP_OP_ROTATE) r = fhe_hip_rotate(c, galois, d, Li, n, FHE_HIP_MEM_DEVICE);
+      else if (op == FHE_HIP_OP_ROTATE) r = fhe_hip_rotate_to(c, galois, d, (const uint64_t *)c->br_buf[s][0], Li, n, FHE_HIP_MEM_DEVICE);
       else if (op == FHE_HIP_OP_ROTATE_MIXED) r = fhe_hip_rotate_mixed(c, galois, d, Li, n, FHE_HIP_MEM_DEVICE);
       else r = fhe_hip_rotate_non_ntt(c, galois, d, Li, n, FHE_HIP_MEM_DEVICE);
       if (r != FHE_HIP_OK) { pipe.fail(r, c->err); break; }

@@ -22,9 +22,10 @@ struct NttArgs {
   const u32 *midx;      // modulus map: limb l of a batch entry uses midx[(l / mdiv) % mper]
   u32 mdiv, mper;
   u32 smod;             // source limb = l % smod (broadcast of a source limb over several outputs)
+  u32 mdiv_inv, mper_inv, smod_inv;  // ceil(2^32 / d) of the three divisors (limb ids stay below 2^16: exact, see limb_div)
   u32 logN, logR;
   u32 l0;               // limb offset: limb id = blockIdx.y + l0
-  u32 skip_diag;        // if nonzero (= Li): skip limbs with (l / Li) == (l % Li)  (relinearisation, j == i)
+  u32 skip_diag;        // if nonzero (= mdiv): skip limbs with (l / mdiv) == (l % mdiv)  (relinearisation, j == i)
   u64 src_bstride, dst_bstride;  // elements between batch entries
   // optional epilogue fused into the forward row pass (the NTT result t never reaches HBM):
   //   epi == 1: out = (src + 2p - t) * c mod p          BaseConverter::rescale inner loop (src/base_converter.cpp:264-271)
@@ -36,11 +37,23 @@ struct NttArgs {
   // inverse row pass only (8-element kernel): the element read is src + pre_k * pre_a  (Decryptor::decrypt, decryptor.cpp:24-35:
   // bx + sx * ax); pre_a = [b](src_bstride)[limb][N] like src, pre_k = [limb][N]; null = plain load
   const u64 *pre_a, *pre_k;
+  // epi == 4 (hybrid rotation, normal limbs): batch entry = 2*ciphertext + half; out = (galois(ax)_j * key_half_j + t) * c
+  // [+ galois(bx)_j on half 0] with epi_src = the INPUT ciphertexts [ct](epi_src_bstride)[2][limb][N] (bx at 0, ax at epi_half),
+  // read through epi_add_perm (null = identity), epi_key0 / epi_key1 = beta / alpha [modulus][N] Montgomery form
+  const u64 *epi_key0, *epi_key1;
+  u64 epi_half;
   u32 epi;
   const u64 *epi_src, *epi_c, *epi_add;
   u64 *epi_out;
   u64 epi_src_bstride, epi_add_bstride, epi_out_bstride;
 };
+
+// Limb ids are wave-uniform and below 2^16, the divisors below 2^16: x / d = hi32(x * ceil(2^32 / d)) exactly (d = 1 apart), two
+// scalar instructions where the compiler's generic 32-bit division costs every thread ~20 vector ones.
+__device__ __forceinline__ u32 limb_div(u32 x, u32 d, u32 inv) { return d == 1 ? x : __umulhi(x, inv); }
+__device__ __forceinline__ u32 limb_mod(u32 x, u32 d, u32 inv) { return x - limb_div(x, d, inv) * d; }
+__device__ __forceinline__ u32 limb_modulus(const NttArgs &a, u32 l) { return a.midx[limb_mod(limb_div(l, a.mdiv, a.mdiv_inv), a.mper, a.mper_inv)]; }
+__device__ __forceinline__ u32 limb_source(const NttArgs &a, u32 l) { return limb_mod(l, a.smod, a.smod_inv); }
 
 // LDS hand-off inside one wave (a 256-element row is owned by 32 consecutive lanes of one wave)
 __device__ __forceinline__ void wave_lds_sync() {
@@ -145,11 +158,11 @@ __global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
   const u32 tid = threadIdx.x, rloc = tid >> 5, t = tid & 31;
   const u32 row = blockIdx.x * (blockDim.x >> 5) + rloc;  // 8 rows per workgroup (R < 8: all R rows, 32 * R threads)
   const u32 l = blockIdx.y + a.l0, b = blockIdx.z;
-  const u32 m = a.midx[(l / a.mdiv) % a.mper];
+  const u32 m = limb_modulus(a, l);
   const PrimeC P = a.primes[m];
   const u64 N = 1ull << a.logN;
   const u64 *__restrict__ tw = a.tw + (u64)m * N;
-  const u64 *s = a.src + (u64)b * a.src_bstride + (u64)(l % a.smod) * N + (u64)row * 256;
+  const u64 *s = a.src + (u64)b * a.src_bstride + (u64)limb_source(a, l) * N + (u64)row * 256;
   u64 *d = a.dst + (u64)b * a.dst_bstride + (u64)l * N + (u64)row * 256;
   u64 *L = lds + rloc * ROW8_LDS;
   const u32 baseA = (1u << a.logR) + row;
@@ -202,6 +215,22 @@ __global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
     if constexpr (EPI == 0) {
       DBG_RANGE(v.x, P.p, 2); DBG_RANGE(v.y, P.p, 2);
       *reinterpret_cast<ulonglong2 *>(&d[el]) = v;
+    } else if constexpr (EPI == 4) {
+      // tail of approximated_mod_down (src/base_converter.cpp:227-240) for both halves of a rotation, with the key product of the
+      // normal limbs (src/evaluator.cpp:373-384) and "+ galois(bx)" (:394-398) formed here from the input ciphertext
+      const u32 h = b & 1;
+      const u64 cm = a.epi_c[m];
+      const u64 *cb = a.epi_src + (u64)(b >> 1) * a.epi_src_bstride + (u64)l * N;
+      const u32 idx = row * 256 + el;
+      uint2 pi = make_uint2(idx, idx + 1);
+      if (a.epi_add_perm) pi = *reinterpret_cast<const uint2 *>(&a.epi_add_perm[idx]);
+      const u64 x0 = cb[a.epi_half + pi.x], x1 = cb[a.epi_half + pi.y];
+      const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(&(h ? a.epi_key1 : a.epi_key0)[(u64)m * N + idx]);
+      u64 r0 = csub(mont_mul<SP>(cm, mont_mul<SP>(kv.x, x0, P) + v.x, P), P.p);
+      u64 r1 = csub(mont_mul<SP>(cm, mont_mul<SP>(kv.y, x1, P) + v.y, P), P.p);
+      if (!h) { r0 = csub(r0 + cb[pi.x], P.p); r1 = csub(r1 + cb[pi.y], P.p); }
+      DBG_RANGE(r0, P.p, 3); DBG_RANGE(r1, P.p, 3);
+      *reinterpret_cast<ulonglong2 *>(&a.epi_out[(u64)b * a.epi_out_bstride + (u64)l * N + idx]) = make_ulonglong2(r0, r1);
     } else {
       const u64 off = (u64)l * N + (u64)row * 256 + el;
       const ulonglong2 h = *reinterpret_cast<const ulonglong2 *>(&a.epi_src[(u64)b * a.epi_src_bstride + off]);
@@ -243,17 +272,17 @@ __global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
 
 // Row pass of the inverse NTT, 8 elements per thread (mirror of ntt_rows8_fwd_kernel): spans 1, 2 | 4, 8, 16 | 32, 64, 128;
 // coalesced 16-byte loads (optionally gathered through a galois index table), output lazy in [0,2p) for the column pass.
-template <bool SP>
+template <bool SP, bool PRE = false>
 __global__ __launch_bounds__(256) void ntt_rows8_inv_kernel(NttArgs a) {
   __shared__ __attribute__((aligned(16))) u64 lds[8 * ROW8_LDS];
   const u32 tid = threadIdx.x, rloc = tid >> 5, t = tid & 31;
   const u32 row = blockIdx.x * (blockDim.x >> 5) + rloc;  // 8 rows per workgroup (R < 8: all R rows, 32 * R threads)
   const u32 l = blockIdx.y + a.l0, b = blockIdx.z;
-  const u32 m = a.midx[(l / a.mdiv) % a.mper];
+  const u32 m = limb_modulus(a, l);
   const PrimeC P = a.primes[m];
   const u64 N = 1ull << a.logN;
   const u64 *__restrict__ tw = a.tw + (u64)m * N;
-  const u64 *s = a.src + (u64)b * a.src_bstride + (u64)(l % a.smod) * N + (u64)row * 256;
+  const u64 *s = a.src + (u64)b * a.src_bstride + (u64)limb_source(a, l) * N + (u64)row * 256;
   u64 *d = a.dst + (u64)b * a.dst_bstride + (u64)l * N + (u64)row * 256;
   u64 *L = lds + rloc * ROW8_LDS;
   const u32 baseA = (1u << a.logR) + row;
@@ -269,8 +298,8 @@ __global__ __launch_bounds__(256) void ntt_rows8_inv_kernel(NttArgs a) {
     } else {
       v = *reinterpret_cast<const ulonglong2 *>(&s[el]);
     }
-    if (a.pre_a) {
-      const u64 lo = (u64)(l % a.smod) * N + (u64)row * 256 + el;
+    if constexpr (PRE) {  // Decryptor::decrypt: the element is bx + sx * ax (NttArgs::pre_a)
+      const u64 lo = (u64)limb_source(a, l) * N + (u64)row * 256 + el;
       const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(&a.pre_a[(u64)b * a.src_bstride + lo]);
       const ulonglong2 k = *reinterpret_cast<const ulonglong2 *>(&a.pre_k[lo]);
       v.x = csub(mulmod_full<SP>(k.x, x.x, P) + csub(v.x, P.p), P.p);
@@ -318,13 +347,14 @@ __global__ __launch_bounds__(256) void ntt_rows8_inv_kernel(NttArgs a) {
 // Replaces: forward row pass + key product + two inverse row passes (three round trips through HBM) for the K special limbs.
 // ---------------------------------------------------------------------------------------------
 struct RotSpArgs {
-  u64 *e0, *e1;                  // [b][nl][N]: e0 holds the column-pass output of the special limbs on entry
+  u64 *e0, *e1;                  // [b](estride)[first_limb + k][N]: e0 holds the column-pass output of the special limbs on entry
+  u64 estride;                   // elements between batch entries
   const u64 *beta_m, *alpha_m;   // [L+K][N] Montgomery form
   const u64 *tw_fwd, *tw_inv;
   const PrimeC *primes;
   u32 first_mod;                 // modulus index of the first special limb (= L)
-  u32 first_limb;                // its limb position inside an entry (= Li)
-  u32 nl, logN, logR;
+  u32 first_limb;                // its limb position inside an entry
+  u32 logN, logR;
 };
 
 template <bool SP>
@@ -337,7 +367,7 @@ __global__ __launch_bounds__(256) void rot_special_rows8_kernel(RotSpArgs a) {
   const u64 N = 1ull << a.logN;
   const u64 *__restrict__ twf = a.tw_fwd + (u64)m * N;
   const u64 *__restrict__ twi = a.tw_inv + (u64)m * N;
-  const u64 off = ((u64)b * a.nl + a.first_limb + blockIdx.y) * N + (u64)row * 256;
+  const u64 off = (u64)b * a.estride + (u64)(a.first_limb + blockIdx.y) * N + (u64)row * 256;
   u64 *L = lds + rloc * ROW8_LDS;
   const u32 baseA = (1u << a.logR) + row;
   const u32 c = t >> 2, r = t & 3, p0 = row8_pos(8 * t);
@@ -428,13 +458,13 @@ __global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs
   __shared__ u64 lds[R * CS];
   const u32 tid = threadIdx.x;
   const u32 l = blockIdx.y + a.l0, b = blockIdx.z;
-  if (a.skip_diag && (l / a.skip_diag) == (l % a.skip_diag)) return;
-  const u32 m = a.midx[(l / a.mdiv) % a.mper];
+  if (a.skip_diag) { const u32 q = limb_div(l, a.mdiv, a.mdiv_inv); if (q == l - q * a.mdiv) return; }  // skip_diag == mdiv (host-checked)
+  const u32 m = limb_modulus(a, l);
   const PrimeC P = a.primes[m];
   const u64 N = 1ull << a.logN;
   const u64 *__restrict__ tw = a.tw + (u64)m * N;
   const u32 col0 = blockIdx.x * CT;
-  const u64 *s = a.src + (u64)b * a.src_bstride + (u64)(l % a.smod) * N + col0;
+  const u64 *s = a.src + (u64)b * a.src_bstride + (u64)limb_source(a, l) * N + col0;
   u64 *d = a.dst + (u64)b * a.dst_bstride + (u64)l * N + col0;
   const u64 nscale = (INVERSE && a.inv_scale) ? a.inv_scale[m] : P.ninv_m;
 

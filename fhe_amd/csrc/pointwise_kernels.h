@@ -93,14 +93,20 @@ __global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
 #pragma unroll
     for (int w = 0; w < 6; ++w) acc[t][w] = 0;
   }
-  auto term = [&](u32 k, u64 xk) {
-    [[maybe_unused]] const PrimeC PS = a.primes[a.src_first + k];
-    u64 t0;  // canonical digit [x_k * inv_k] mod the source prime
-    if constexpr (PRE) t0 = xk; else t0 = csub(mont_mul<SP>(a.inv_m[k], xk, PS), PS.p);
+  // hat factors of one source limb for the thread's targets: uniform, so they travel through the scalar cache into SGPRs.
+  // They are requested one term ahead (hn), like the source limbs: a scalar load waited for right where it is used costs
+  // its whole latency ten times per loop iteration.
+  u64 hc[BCONV_TC], hn[BCONV_TC];
+  auto load_hat = [&](u64 (&h)[BCONV_TC], u32 k) {
+#pragma unroll
+    for (int t = 0; t < BCONV_TC; ++t) h[t] = a.hat_m[(u64)tt[t] * a.hat_stride + k];
+  };
+  // one source limb into the accumulators of targets [t_lo, t_hi)
+  auto term = [&](u64 t0, const u64 (&hat)[BCONV_TC], int t_lo, int t_hi) {
     const u32 b0 = (u32)t0, b1 = (u32)(t0 >> 32);
 #pragma unroll
-    for (int t = 0; t < BCONV_TC; ++t) {
-      const u64 h = a.hat_m[(u64)tt[t] * a.hat_stride + k];  // uniform: scalar load, scalar split
+    for (int t = t_lo; t < t_hi; ++t) {
+      const u64 h = hat[t];
       const u32 h0 = (u32)h & 0x1FFFFFu, h1 = (u32)(h >> 21) & 0x1FFFFFu, h2 = (u32)(h >> 42);
       acc[t][0] = mad_wide(h0, b0, acc[t][0]);
       acc[t][1] = mad_wide(h1, b0, acc[t][1]);
@@ -110,20 +116,40 @@ __global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
       acc[t][5] = mad_wide(h2, b1, acc[t][5]);
     }
   };
-  // source limbs are requested one term ahead, ping-pong between two registers (no copy, so no wait at the loop end);
-  // indices are clamped instead of branching, the odd last term is peeled
+  auto digit = [&](u32 k, u64 xk) {  // canonical digit [x_k * inv_k] mod the source prime
+    if constexpr (PRE) return xk;
+    else { const PrimeC PS = a.primes[a.src_first + k]; return csub(mont_mul<SP>(a.inv_m[k], xk, PS), PS.p); }
+  };
+  // Source limbs and hat factors are requested one term ahead, ping-pong between two register sets (no copy, so no wait at the
+  // loop end); indices are clamped instead of branching, the odd last term is peeled.  Scalar loads return out of order, so
+  // waiting for one of them waits for all: the next term's factors are requested only AFTER the first target of the current
+  // term has forced that wait, and the remaining 24 multiply-adds of the term cover their latency.
   const u32 last = a.nsrc - 1;
-  u64 xa = sp[0], xb;
+  const u32 l1 = last < 1 ? last : 1, l2 = last < 2 ? last : 2;
+  u64 xa = sp[0], xb = sp[(u64)l1 * a.N], xc, xd;  // source limbs run TWO terms ahead (four registers, unrolled by four)
+  load_hat(hc, 0);
   u32 k = 0;
-  for (; k + 1 < a.nsrc; k += 2) {
-    xb = sp[(u64)(k + 1) * a.N];
+  auto clampk = [&](u32 q) { return q < last ? q : last; };
+  auto step = [&](u32 kk, u64 xcur, u64 &xfar, u64 (&hcur)[BCONV_TC], u64 (&hnext)[BCONV_TC]) {
+    xfar = sp[(u64)clampk(kk + 2) * a.N];
+    const u64 dg = digit(kk, xcur);
+    term(dg, hcur, 0, 1);
     __builtin_amdgcn_sched_barrier(0);
-    term(k, xa);
-    xa = sp[(u64)(k + 2 < last ? k + 2 : last) * a.N];
+    load_hat(hnext, clampk(kk + 1));
     __builtin_amdgcn_sched_barrier(0);
-    term(k + 1, xb);
+    term(dg, hcur, 1, BCONV_TC);
+  };
+  (void)l2;
+  for (; k + 3 < a.nsrc; k += 4) {
+    step(k, xa, xc, hc, hn);
+    step(k + 1, xb, xd, hn, hc);
+    step(k + 2, xc, xa, hc, hn);
+    step(k + 3, xd, xb, hn, hc);
   }
-  if (k < a.nsrc) term(k, xa);
+  // up to three terms left: xa, xb hold limbs k and k+1 (clamped), hc the factors of term k
+  if (k < a.nsrc) { step(k, xa, xc, hc, hn); ++k;
+    if (k < a.nsrc) { step(k, xb, xd, hn, hc); ++k;
+      if (k < a.nsrc) { term(digit(k, xc), hc, 0, BCONV_TC); ++k; } } }
 #pragma unroll
   for (int t = 0; t < BCONV_TC; ++t) {
     const PrimeC PT = a.primes[a.tgt_first + tt[t]];
@@ -133,27 +159,18 @@ __global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
   }
 }
 
-// key multiply of apply_rotation_key (src/evaluator.cpp:373-384): e0 = ext * beta[idx], e1 = ext * alpha[idx],
-// idx = midx[cm] (cm < Li ? cm : L + cm - Li).  ext/e0/e1 = [b][nl][N]; keys [L+K][N] Montgomery form.  When `norm` is
-// given, limbs cm < nnorm are read from norm = [b](norm_bstride)[nnorm][N] instead of ext (the NTT-domain normal limbs of the
-// extended polynomial are the input itself); with norm_perm element d is norm[..][norm_perm[d]] (apply_galois fused into the read).
+// key multiply of apply_rotation_key_non_ntt (src/evaluator.cpp:544-556): e0 = ext * beta[idx], e1 = ext * alpha[idx],
+// idx = midx[cm] (cm < Li ? cm : L + cm - Li).  ext/e0/e1 = [b][nl][N]; keys [L+K][N] Montgomery form.  (The NTT-domain
+// rotation forms its key products inside rot_special_rows8_kernel and the mod-down tail, NttArgs::epi == 4.)
 template <bool SP>
 __global__ __launch_bounds__(PW_THREADS) void rot_keymul_kernel(u64 *e0, u64 *e1, const u64 *ext, const u64 *beta_m,
-                                                                const u64 *alpha_m, const PrimeC *primes, const u32 *midx, u32 nl,
-                                                                u64 N, const u64 *norm, u64 norm_bstride, u32 nnorm, const u32 *norm_perm) {
+                                                                const u64 *alpha_m, const PrimeC *primes, const u32 *midx, u32 nl, u64 N) {
   const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
   const u32 cm = blockIdx.y, b = blockIdx.z;
   const u32 m = midx[cm];
   const PrimeC P = primes[m];
   const u64 o = ((u64)b * nl + cm) * N + d;
-  ulonglong2 x;
-  if (norm && cm < nnorm) {
-    const u64 *xl = norm + (u64)b * norm_bstride + (u64)cm * N;
-    if (norm_perm) { const uint2 pi = *reinterpret_cast<const uint2 *>(&norm_perm[d]); x = make_ulonglong2(xl[pi.x], xl[pi.y]); }
-    else x = ld2(xl + d);
-  } else {
-    x = ld2(ext + o);
-  }
+  const ulonglong2 x = ld2(ext + o);
   const ulonglong2 kb = ld2(beta_m + (u64)m * N + d), ka = ld2(alpha_m + (u64)m * N + d);
   st2c(e0 + o, csub(mont_mul<SP>(kb.x, x.x, P), P.p), csub(mont_mul<SP>(kb.y, x.y, P), P.p), P.p, 15);
   st2c(e1 + o, csub(mont_mul<SP>(ka.x, x.x, P), P.p), csub(mont_mul<SP>(ka.y, x.y, P), P.p), P.p, 15);

@@ -78,6 +78,7 @@ def load_library():
         "fhe_hip_mul_relin_rescale": (i, [vp, vp, vp, vp, u32, sz, i]),
         "fhe_hip_rotate": (i, [vp, u64, vp, u32, sz, i]),
         "fhe_hip_rotate_non_ntt": (i, [vp, u64, vp, u32, sz, i]),
+        "fhe_hip_rotate_to": (i, [vp, u64, vp, vp, u32, sz, i]),
         "fhe_hip_load_mixed_rot_key": (i, [vp, u64, vp, vp, i]),
         "fhe_hip_rotate_mixed": (i, [vp, u64, vp, u32, sz, i]),
         "fhe_hip_decrypt": (i, [vp, vp, vp, vp, u32, sz, i]),
@@ -103,7 +104,7 @@ EXPORTED_SYMBOLS = [
     "fhe_hip_mod_up", "fhe_hip_mod_down", "fhe_hip_rescale", "fhe_hip_load_mult_key", "fhe_hip_load_rot_key",
     "fhe_hip_add", "fhe_hip_multiply_plain", "fhe_hip_cross_mult", "fhe_hip_relin_only", "fhe_hip_relinearize",
     "fhe_hip_mul_relin_rescale", "fhe_hip_rotate", "fhe_hip_rotate_non_ntt", "fhe_hip_load_mixed_rot_key", "fhe_hip_rotate_mixed", "fhe_hip_decrypt", "fhe_hip_encrypt", "fhe_hip_profile_enable", "fhe_hip_profile_reset",
-    "fhe_hip_profile_get", "fhe_hip_batch_run", "fhe_hip_conv_to_normal", "fhe_hip_mul_relin_rescale_noalloc", "fhe_hip_set_tuning", "fhe_hip_debug_violations",
+    "fhe_hip_profile_get", "fhe_hip_batch_run", "fhe_hip_conv_to_normal", "fhe_hip_mul_relin_rescale_noalloc", "fhe_hip_set_tuning", "fhe_hip_debug_violations", "fhe_hip_rotate_to",
 ]
 OP_MUL_RELIN_RESCALE, OP_ROTATE, OP_ROTATE_MIXED, OP_ROTATE_NON_NTT = 1, 2, 3, 4
 TUNE_RELIN_GROUP = 1
@@ -309,6 +310,13 @@ class HipContext:
         _need(ct=(ct, batch * 2 * Li * self.N))
         self._chk(self.lib.fhe_hip_rotate(self.h, galois, c, Li, batch, kind))
         return ct
+
+    def rotate_to(self, galois, out, ct, Li, batch=1):
+        """fhe_hip_rotate_to: the rotation out of place (out != ct; ct is left untouched)."""
+        (o, c), kind = _same_kind(out, ct)
+        _need(out=(out, batch * 2 * Li * self.N), ct=(ct, batch * 2 * Li * self.N))
+        self._chk(self.lib.fhe_hip_rotate_to(self.h, galois, o, c, Li, batch, kind))
+        return out
 
     def rotate_non_ntt(self, galois, ct, Li, batch=1):
         """Evaluator::rotate_slots_non_ntt (src/evaluator.cpp:138-146, 327-339, 520-574): ct in the power basis, in place."""

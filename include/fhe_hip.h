@@ -104,6 +104,11 @@ int fhe_hip_mul_relin_rescale(fhe_hip_ctx *ctx, uint64_t *out, const uint64_t *c
 /* Evaluator::rotate_slots(Cipher*, RotKey const&) (:128-136, 299-311, 343-399): ct = [batch][2][Li][N]
  * in place with the RotKey loaded for `galois`; galois == 0 is a no-op (:303-304). */
 int fhe_hip_rotate(fhe_hip_ctx *ctx, uint64_t galois, uint64_t *ct, uint32_t Li, size_t batch, int mem_kind);
+/* The same rotation out of place: in, out = [batch][2][Li][N], out != in, in is left untouched (the reference's method works on
+ * its argument; a batch on the device usually wants a separate result).  The device pipeline is out of place by nature (it
+ * reads the input through the galois index table until its last kernel), so this form saves the copy fhe_hip_rotate makes for
+ * device buffers.  galois == 0 copies in to out. */
+int fhe_hip_rotate_to(fhe_hip_ctx *ctx, uint64_t galois, uint64_t *out, const uint64_t *in, uint32_t Li, size_t batch, int mem_kind);
 
 /* Evaluator::rotate_slots_non_ntt(Cipher*, RotKey const&) (src/evaluator.cpp:138-146, 327-339, 520-574): ct = [batch][2][Li][N]
  * in the POWER basis, in place; apply_galois_non_ntt on both halves, then the hybrid key switch with every limb taken

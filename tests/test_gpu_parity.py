@@ -587,3 +587,41 @@ def test_full_size_relinearisation_against_python_integers():
         vals = [ntt_value_at(dig[j], d, logN, si, pi) for j in range(Li)]
         assert int(got[0][i][d]) == (sum(vals[j] * int(beta[j][i][d]) for j in range(Li)) + int(ct3[0][i][d])) % pi
         assert int(got[1][i][d]) == (sum(vals[j] * int(alpha[j][i][d]) for j in range(Li)) + int(ct3[1][i][d])) % pi
+
+
+@pytest.mark.parametrize("logN,L,K,Li", [(12, 4, 4, 4), (10, 3, 2, 2), (13, 5, 3, 4)])
+def test_rotate_out_of_place_matches_in_place_and_oracle(logN, L, K, Li):
+    """fhe_hip_rotate_to (nine-launch pipeline: galois applied inside the loads, key product of the normal limbs and + galois(bx)
+    in the mod-down tail) against the oracle and against fhe_hip_rotate, which forms the same result beside the input and copies."""
+    o, g = ctx_pair(logN, L, K)
+    sx, ext = o.keygen_sk(seed=300 + logN)
+    B = 3
+    ct = np.stack([np.stack([rand_poly(o, range(Li), 310 + 2 * b), rand_poly(o, range(Li), 311 + 2 * b)]) for b in range(B)])
+    for offset in (1, 5):
+        gal = o.rotation_galois(offset)
+        rkb, rka = o.keygen_rot(sx, ext, gal, seed=320 + offset)
+        g.load_rot_key(gal, dev(rkb), dev(rka))
+        want = np.stack([np.stack(o.rotate(ct[b, 0], ct[b, 1], gal, rkb, rka)) for b in range(B)])
+        src = dev(ct)
+        out = torch.full((B, 2, Li, o.N), -1, dtype=torch.int64, device="cuda")
+        g.rotate_to(gal, out, src, Li, batch=B)
+        assert np.array_equal(host(out), want) and np.array_equal(host(src), ct)  # input untouched
+        inplace = dev(ct)
+        g.rotate(gal, inplace, Li, batch=B)
+        assert np.array_equal(host(inplace), want)
+        hout = np.zeros_like(ct)
+        g.rotate_to(gal, hout, ct.copy(), Li, batch=B)  # host buffers
+        assert np.array_equal(hout, want)
+    # galois == 1: a key switch with the identity automorphism (no index table); galois == 0: copy
+    rkb, rka = o.keygen_rot(sx, ext, 1, seed=399)
+    g.load_rot_key(1, dev(rkb), dev(rka))
+    want = np.stack([np.stack(o.rotate(ct[b, 0], ct[b, 1], 1, rkb, rka)) for b in range(B)])
+    out = torch.zeros((B, 2, Li, o.N), dtype=torch.int64, device="cuda")
+    g.rotate_to(1, out, dev(ct), Li, batch=B)
+    assert np.array_equal(host(out), want)
+    g.rotate_to(0, out, dev(ct), Li, batch=B)
+    assert np.array_equal(host(out), ct)
+    src = dev(ct)
+    with pytest.raises(fhe_amd.FheHipError) as e:
+        g.rotate_to(3, src, src, Li, batch=B)
+    assert e.value.code == -1
