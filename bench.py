@@ -254,7 +254,7 @@ def read_profile_json(kind, workload):
 class Setup:
     """One workload on one context: synthetic HBM-resident inputs and the step() that runs the hot path over them."""
 
-    def __init__(self, workload, B, local_rank, rank, sb=None, relin_group=0):
+    def __init__(self, workload, B, local_rank, rank, sb=None, relin_group=0, ntt_chunk=0):
         import torch
         import fhe_amd
         self.workload = workload
@@ -267,6 +267,8 @@ class Setup:
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         if relin_group:
             ctx.set_tuning(fhe_amd.hip.TUNE_RELIN_GROUP, relin_group)
+        if ntt_chunk:
+            ctx.set_tuning(fhe_amd.hip.TUNE_NTT_CHUNK, ntt_chunk)
         gen = torch.Generator(device="cuda").manual_seed(0x5EED0000 + rank)
 
         def rnd(*shape):  # uniform residues below 2^61 (< every prime of the table)
@@ -444,6 +446,7 @@ def main():
                          "sustained clocks (a 5 ms NTT run measures 1.96 M limb-NTT/s, a 0.4 s one 2.40 M)")
     ap.add_argument("--no-ntt-n16", action="store_true", help="skip the ntt_n16 sub-record of the default (c3) run")
     ap.add_argument("--relin-group", type=int, default=0, help="FHE_HIP_TUNE_RELIN_GROUP (0 = library default)")
+    ap.add_argument("--ntt-chunk", type=int, default=0, help="FHE_HIP_TUNE_NTT_CHUNK (0 = library default)")
     ap.add_argument("--e2e", action="store_true",
                     help="c3 / c5 only: also time the same operations end to end with inputs and results resident on rank 0 only "
                          "(ShardedEvaluator: chunked scatter / compute / gather), reported beside the compute-only value")
@@ -487,7 +490,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    su = Setup(args.workload, args.batch, local_rank, rank, sb, args.relin_group)
+    su = Setup(args.workload, args.batch, local_rank, rank, sb, args.relin_group, args.ntt_chunk)
     logN, L, K, Li, N, B = su.logN, su.L, su.K, su.Li, su.N, su.B
     elapsed, prof = su.timed(args.steps, args.warmup, args.prewarm, barrier)
     elapsed = max_over_ranks(elapsed)

@@ -85,6 +85,7 @@ struct fhe_hip_ctx {
   unsigned char *scratch = nullptr;
   bool fixed_ws = false; size_t fixed_used = 0;
   uint32_t relin_group = 0;  // output limbs per relinearisation pass (0 = all Li at once): fhe_hip_set_tuning
+  uint32_t ntt_chunk = 0;    // limbs per pass pair of fhe_hip_ntt_forward / _backward (0 = as many as one grid takes)
   void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[4] = {0, 0, 0, 0};
   // per-launch timing: consecutive launches share an event (end of one = start of the next) while nothing else was enqueued
@@ -821,8 +822,9 @@ static int ntt_api(fhe_hip_ctx *c, uint64_t *limbs, const uint32_t *moduli_idx, 
     HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(c->d_idx, c->h_idx.data(), n_limbs * sizeof(u32), hipMemcpyHostToDevice, c->stream)));
   }
   u32 *dm = c->d_idx;
-  for (size_t off = 0; off < n_limbs; off += 32768) {
-    const u32 n = (u32)((n_limbs - off < 32768) ? n_limbs - off : 32768);
+  const size_t step = c->ntt_chunk ? c->ntt_chunk : 32768;
+  for (size_t off = 0; off < n_limbs; off += step) {
+    const u32 n = (u32)((n_limbs - off < step) ? n_limbs - off : step);
     NttPlan p{d + off * c->N, d + off * c->N, dm + off, 1, n, n, n, 1, 0, 0};
     TRY(ntt_run(c, p, inverse));
   }
@@ -1099,6 +1101,7 @@ int fhe_hip_mul_relin_rescale_noalloc(fhe_hip_ctx *c, uint64_t *out, const uint6
 int fhe_hip_set_tuning(fhe_hip_ctx *c, int knob, uint64_t value) {
   TRY(check_ctx(c));
   if (knob == FHE_HIP_TUNE_RELIN_GROUP) { c->relin_group = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return FHE_HIP_OK; }
+  if (knob == FHE_HIP_TUNE_NTT_CHUNK) { c->ntt_chunk = value > 32768 ? 32768u : (uint32_t)value; return FHE_HIP_OK; }
   FAIL(c, FHE_HIP_ERR_ARG, "unknown tuning knob");
 }
 

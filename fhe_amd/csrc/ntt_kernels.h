@@ -55,6 +55,15 @@ __device__ __forceinline__ u32 limb_mod(u32 x, u32 d, u32 inv) { return x - limb
 __device__ __forceinline__ u32 limb_modulus(const NttArgs &a, u32 l) { return a.midx[limb_mod(limb_div(l, a.mdiv, a.mdiv_inv), a.mper, a.mper_inv)]; }
 __device__ __forceinline__ u32 limb_source(const NttArgs &a, u32 l) { return limb_mod(l, a.smod, a.smod_inv); }
 
+// Gather of the element pair (d, d+1), d even, through a galois index table.  In the bit-reversed order the automorphism maps
+// d and d+1 to the two halves of ONE aligned pair (they differ in the top bit of the exponent index, and multiplying by an
+// odd g keeps that a top-bit difference), so a single 16-byte load fetches both; the table entry's low bit says whether
+// they are swapped.
+__device__ __forceinline__ ulonglong2 gather_pair(const u64 *limb, u32 pd) {
+  const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&limb[pd & ~1u]);
+  return (pd & 1u) ? make_ulonglong2(v.y, v.x) : v;
+}
+
 // LDS hand-off inside one wave (a 256-element row is owned by 32 consecutive lanes of one wave)
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -222,13 +231,13 @@ __global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
       const u64 cm = a.epi_c[m];
       const u64 *cb = a.epi_src + (u64)(b >> 1) * a.epi_src_bstride + (u64)l * N;
       const u32 idx = row * 256 + el;
-      uint2 pi = make_uint2(idx, idx + 1);
-      if (a.epi_add_perm) pi = *reinterpret_cast<const uint2 *>(&a.epi_add_perm[idx]);
-      const u64 x0 = cb[a.epi_half + pi.x], x1 = cb[a.epi_half + pi.y];
+      const u32 pd = a.epi_add_perm ? a.epi_add_perm[idx] : idx;
+      const ulonglong2 xx = gather_pair(cb + a.epi_half, pd);
+      const u64 x0 = xx.x, x1 = xx.y;
       const ulonglong2 kv = *reinterpret_cast<const ulonglong2 *>(&(h ? a.epi_key1 : a.epi_key0)[(u64)m * N + idx]);
       u64 r0 = csub(mont_mul<SP>(cm, mont_mul<SP>(kv.x, x0, P) + v.x, P), P.p);
       u64 r1 = csub(mont_mul<SP>(cm, mont_mul<SP>(kv.y, x1, P) + v.y, P), P.p);
-      if (!h) { r0 = csub(r0 + cb[pi.x], P.p); r1 = csub(r1 + cb[pi.y], P.p); }
+      if (!h) { const ulonglong2 bb = gather_pair(cb, pd); r0 = csub(r0 + bb.x, P.p); r1 = csub(r1 + bb.y, P.p); }
       DBG_RANGE(r0, P.p, 3); DBG_RANGE(r1, P.p, 3);
       *reinterpret_cast<ulonglong2 *>(&a.epi_out[(u64)b * a.epi_out_bstride + (u64)l * N + idx]) = make_ulonglong2(r0, r1);
     } else {
@@ -256,8 +265,7 @@ __global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
           ulonglong2 ad;
           if (a.epi_add_perm) {
             const u64 *al = a.epi_add + (u64)b * a.epi_add_bstride + (u64)l * N;
-            const uint2 pi = *reinterpret_cast<const uint2 *>(&a.epi_add_perm[row * 256 + el]);
-            ad = make_ulonglong2(al[pi.x], al[pi.y]);
+            ad = gather_pair(al, a.epi_add_perm[row * 256 + el]);
           } else {
             ad = *reinterpret_cast<const ulonglong2 *>(&a.epi_add[(u64)b * a.epi_add_bstride + off]);
           }
@@ -293,8 +301,7 @@ __global__ __launch_bounds__(256) void ntt_rows8_inv_kernel(NttArgs a) {
     ulonglong2 v;
     if (a.perm) {
       const u64 *sl = s - (u64)row * 256;  // limb base
-      const uint2 pi = *reinterpret_cast<const uint2 *>(&a.perm[row * 256 + el]);
-      v = make_ulonglong2(sl[pi.x], sl[pi.y]);
+      v = gather_pair(sl, a.perm[row * 256 + el]);
     } else {
       v = *reinterpret_cast<const ulonglong2 *>(&s[el]);
     }

@@ -171,6 +171,9 @@ int fhe_hip_mul_relin_rescale_noalloc(fhe_hip_ctx *ctx, uint64_t *out, const uin
  *   of the Li^2 digit NTTs is produced and consumed value limbs at a time, which bounds its footprint to
  *   batch * value * Li * N * 8 bytes; results do not depend on it. */
 #define FHE_HIP_TUNE_RELIN_GROUP 1
+/*   FHE_HIP_TUNE_NTT_CHUNK: limbs per column-pass / row-pass launch pair of fhe_hip_ntt_forward / _backward (0 = the whole call,
+ *   the default): with a chunk whose limbs fit the 256 MiB Infinity Cache the second pass reads what the first just wrote. */
+#define FHE_HIP_TUNE_NTT_CHUNK 2
 int fhe_hip_set_tuning(fhe_hip_ctx *ctx, int knob, uint64_t value);
 
 /* Debug build support (reference analogue: the non-release -DCHECK_STRICTMOD range asserts, CMakeCompilers.txt:26).
