@@ -66,6 +66,9 @@ while time.time() < t_end:
     for b in range(B):
         wb, wa = o.mul_relin_rescale(c0[b, 0], c0[b, 1], c1[b, 0], c1[b, 1], beta, alpha)
         check("mul_relin_rescale", host(out)[b], np.stack([wb, wa]))
+    if B * (9 * Li - 2) * N * 8 <= fhe_amd.hip.NOALLOC_SCRATCH_BYTES:
+        out2 = torch.zeros_like(out); g.mul_relin_rescale_noalloc(out2, dev(c0), dev(c1), Li, batch=B)
+        check("mul_relin_rescale_noalloc", host(out2), host(out))
     # rotations with a random galois element
     gal = int(rng.integers(1, N)) * 2 + 1
     rkb, rka = uni(range(L + K)), uni(range(L + K))
@@ -74,6 +77,7 @@ while time.time() < t_end:
     for b in range(B):
         wb, wa = o.rotate(c0[b, 0], c0[b, 1], gal, rkb, rka)
         check("rotate", host(d)[b], np.stack([wb, wa]))
+    d2 = torch.zeros_like(d); g.rotate_to(gal, d2, dev(c0), Li, batch=B); check("rotate_to", host(d2), host(d))
     d = dev(c1); g.rotate_non_ntt(gal, d, Li, batch=B)
     for b in range(B):
         wb, wa = o.rotate_non_ntt(c1[b, 0], c1[b, 1], gal, rkb, rka)
