@@ -254,7 +254,7 @@ def read_profile_json(kind, workload):
 class Setup:
     """One workload on one context: synthetic HBM-resident inputs and the step() that runs the hot path over them."""
 
-    def __init__(self, workload, B, local_rank, rank, sb=None, relin_group=0, ntt_chunk=0):
+    def __init__(self, workload, B, local_rank, rank, sb=None, relin_group=0, ntt_chunk=0, onepass=1):
         import torch
         import fhe_amd
         self.workload = workload
@@ -269,6 +269,8 @@ class Setup:
             ctx.set_tuning(fhe_amd.hip.TUNE_RELIN_GROUP, relin_group)
         if ntt_chunk:
             ctx.set_tuning(fhe_amd.hip.TUNE_NTT_CHUNK, ntt_chunk)
+        if not onepass:
+            ctx.set_tuning(fhe_amd.hip.TUNE_ONEPASS, 0)
         gen = torch.Generator(device="cuda").manual_seed(0x5EED0000 + rank)
 
         def rnd(*shape):  # uniform residues below 2^61 (< every prime of the table)
@@ -389,6 +391,10 @@ class Setup:
             ms = kms("bconv_modup")[1] + kms("bconv_moddown")[1]
             kname = "bconv_kernel (mod-up + 2x mod-down)"
             units_per_launch = B
+        elif kms("ntt_fwd_onepass")[0]:  # N <= 2^14: the limb stays in one workgroup's LDS, one kernel per transform
+            launches, ms = kms("ntt_fwd_onepass")
+            kname = "ntt_onepass_fwd_kernel"
+            units_per_launch = B
         else:
             launches = kms("ntt_fwd_cols")[0]
             ms = kms("ntt_fwd_cols")[1] + kms("ntt_fwd_rows")[1]
@@ -447,6 +453,7 @@ def main():
     ap.add_argument("--no-ntt-n16", action="store_true", help="skip the ntt_n16 sub-record of the default (c3) run")
     ap.add_argument("--relin-group", type=int, default=0, help="FHE_HIP_TUNE_RELIN_GROUP (0 = library default)")
     ap.add_argument("--ntt-chunk", type=int, default=0, help="FHE_HIP_TUNE_NTT_CHUNK (0 = library default)")
+    ap.add_argument("--onepass", type=int, default=1, help="FHE_HIP_TUNE_ONEPASS: 0 = column/row pass pair also for N <= 2^14")
     ap.add_argument("--e2e", action="store_true",
                     help="c3 / c5 only: also time the same operations end to end with inputs and results resident on rank 0 only "
                          "(ShardedEvaluator: chunked scatter / compute / gather), reported beside the compute-only value")
@@ -490,7 +497,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    su = Setup(args.workload, args.batch, local_rank, rank, sb, args.relin_group, args.ntt_chunk)
+    su = Setup(args.workload, args.batch, local_rank, rank, sb, args.relin_group, args.ntt_chunk, args.onepass)
     logN, L, K, Li, N, B = su.logN, su.L, su.K, su.Li, su.N, su.B
     elapsed, prof = su.timed(args.steps, args.warmup, args.prewarm, barrier)
     elapsed = max_over_ranks(elapsed)

@@ -85,6 +85,8 @@ struct fhe_hip_ctx {
   unsigned char *scratch = nullptr;
   bool fixed_ws = false; size_t fixed_used = 0;
   uint32_t relin_group = 0;  // output limbs per relinearisation pass (0 = all Li at once): fhe_hip_set_tuning
+  int num_cus = 256;         // persistent kernels size their grids by it
+  uint32_t onepass = 1;      // N = 2^12 .. 2^14: plain NTTs as one kernel with the limb in LDS (FHE_HIP_TUNE_ONEPASS)
   uint32_t ntt_chunk = 0;    // limbs per pass pair of fhe_hip_ntt_forward / _backward (0 = as many as one grid takes)
   void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[4] = {0, 0, 0, 0};
@@ -280,6 +282,27 @@ int launch_rows(fhe_hip_ctx *c, const NttArgs &a, u32 nl, u32 batch) {
   return FHE_HIP_OK;
 }
 
+// one-pass NTT (a whole limb in one workgroup's LDS): N = 2^12 .. 2^14, plain transforms only
+template <bool SP, bool INV>
+int launch_onepass(fhe_hip_ctx *c, const NttArgs &a, u32 nl, u32 batch) {
+  const char *name = INV ? "ntt_inv_onepass" : "ntt_fwd_onepass";
+#define ONE_CASE(LR)                                                                             \
+  case LR: {                                                                                     \
+    dim3 block(OneCfg<LR>::T);                                                                   \
+    const u32 total = nl * batch, slots = (u32)c->num_cus * (64 >> LR);  /* workgroups the LDS lets a CU hold: 4, 2, 1 */ \
+    dim3 pgrid(total < slots ? total : slots);                                                   \
+    if constexpr (INV) LAUNCH(c, name, (ntt_onepass_inv_kernel<SP, LR>), pgrid, block, a, nl, total); \
+    else LAUNCH(c, name, (ntt_onepass_fwd_kernel<SP, LR>), pgrid, block, a, nl, total);          \
+    break;                                                                                       \
+  }
+  switch (c->logR) {
+    ONE_CASE(4) ONE_CASE(5) ONE_CASE(6)
+    default: FAIL(c, FHE_HIP_ERR_RANGE, "internal: one-pass NTT outside N = 2^12 .. 2^14");
+  }
+#undef ONE_CASE
+  return FHE_HIP_OK;
+}
+
 template <bool SP>
 int ntt_run_sp(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
   if (p.nl == 0 || p.batch == 0) return FHE_HIP_OK;
@@ -299,6 +322,11 @@ int ntt_run_sp(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
   first.src = p.src; first.src_bstride = p.src_bstride; first.smod = p.smod; first.smod_inv = inv32(p.smod);
   if (inverse) { first.perm = p.perm; first.pre_a = p.pre_a; first.pre_k = p.pre_k; }
   second.src = p.dst; second.src_bstride = p.dst_bstride; second.smod = p.nl; second.smod_inv = inv32(p.nl);
+  if (c->onepass && c->logR >= 4 && c->logR <= 6 && !p.cols_only && !p.skip_diag && (inverse ? (!p.perm && !p.pre_a) : p.epi == 0)) {
+    if (inverse) TRY((launch_onepass<SP, true>(c, first, p.nl, p.batch)));
+    else TRY((launch_onepass<SP, false>(c, first, p.nl, p.batch)));
+    return FHE_HIP_OK;
+  }
   if (!inverse) {
     TRY((launch_cols<SP, false>(c, first, p.nl, p.batch)));
     if (!p.cols_only) TRY((launch_rows<SP, false>(c, second, p.nl, p.batch)));
@@ -683,6 +711,7 @@ int fhe_hip_ctx_create(fhe_hip_ctx **out, uint32_t logN, uint32_t L, uint32_t K,
   c->device = device; c->logN = logN; c->L = L; c->K = K; c->M = L + K; c->N = 1ull << logN; c->logR = logN - 8;
   const uint32_t M = c->M; const u64 N = c->N;
   if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(FHE_HIP_ERR_HIP); }
+  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256; c->num_cus = cus; }
   c->primes.assign(primes, primes + M);
   c->sp = true;
   for (uint32_t m = 0; m < M; ++m) {
@@ -1101,6 +1130,7 @@ int fhe_hip_mul_relin_rescale_noalloc(fhe_hip_ctx *c, uint64_t *out, const uint6
 int fhe_hip_set_tuning(fhe_hip_ctx *c, int knob, uint64_t value) {
   TRY(check_ctx(c));
   if (knob == FHE_HIP_TUNE_RELIN_GROUP) { c->relin_group = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return FHE_HIP_OK; }
+  if (knob == FHE_HIP_TUNE_ONEPASS) { c->onepass = value ? 1u : 0u; return FHE_HIP_OK; }
   if (knob == FHE_HIP_TUNE_NTT_CHUNK) { c->ntt_chunk = value > 32768 ? 32768u : (uint32_t)value; return FHE_HIP_OK; }
   FAIL(c, FHE_HIP_ERR_ARG, "unknown tuning knob");
 }

@@ -121,8 +121,8 @@ __device__ __forceinline__ void fwd_phase_w(u64 (&e)[1 << LK], const u64 (&w)[(1
 }
 
 // forward phase whose twiddles are the same for every lane (first phase of the column pass: heap indices 1 .. 2^LK - 1)
-template <bool SP, int LK>
-__device__ __forceinline__ void fwd_phase_ua(u64 (&e)[1 << LK], const u64 *__restrict__ tw, const PrimeC &P) {
+template <bool SP, int LK, typename TwPtr>
+__device__ __forceinline__ void fwd_phase_ua(u64 (&e)[1 << LK], TwPtr tw, const PrimeC &P) {
 #pragma unroll
   for (int q = 0; q < LK; ++q) {
     const int half = 1 << (LK - 1 - q);
@@ -135,8 +135,8 @@ __device__ __forceinline__ void fwd_phase_ua(u64 (&e)[1 << LK], const u64 *__res
   }
 }
 
-template <bool SP, int LK>
-__device__ __forceinline__ void inv_phase(u64 (&e)[1 << LK], const u64 *__restrict__ tw, u32 base, const PrimeC &P) {
+template <bool SP, int LK, typename TwPtr>
+__device__ __forceinline__ void inv_phase(u64 (&e)[1 << LK], TwPtr tw, u32 base, const PrimeC &P) {
 #pragma unroll
   for (int q = LK - 1; q >= 0; --q) {
     const int half = 1 << (LK - 1 - q);
@@ -149,6 +149,19 @@ __device__ __forceinline__ void inv_phase(u64 (&e)[1 << LK], const u64 *__restri
         gs_bfly<SP>(e[a], e[a + half], W, P);
       }
     }
+  }
+}
+
+// inverse phase with the twiddles of load_tw already in registers
+template <bool SP, int LK>
+__device__ __forceinline__ void inv_phase_w(u64 (&e)[1 << LK], const u64 (&w)[(1 << LK) - 1], const PrimeC &P) {
+#pragma unroll
+  for (int q = LK - 1; q >= 0; --q) {
+    const int half = 1 << (LK - 1 - q);
+#pragma unroll
+    for (int kk = 0; kk < (1 << q); ++kk)
+#pragma unroll
+      for (int j = 0; j < half; ++j) gs_bfly<SP>(e[kk * 2 * half + j], e[kk * 2 * half + j + half], w[(1 << q) - 1 + kk], P);
   }
 }
 
@@ -722,5 +735,313 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     DBG_RANGE(r00, P.p, 10); DBG_RANGE(r01, P.p, 10); DBG_RANGE(r10, P.p, 10); DBG_RANGE(r11, P.p, 10);
     *reinterpret_cast<ulonglong2 *>(&o[e]) = make_ulonglong2(r00, r01);
     *reinterpret_cast<ulonglong2 *>(&o[half + e]) = make_ulonglong2(r10, r11);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One-pass NTT for N = 2^12 .. 2^14: a whole limb (R = N/256 <= 64 rows of 256) sits in one workgroup's LDS, so the limb is read
+// from and written to HBM once (16 N bytes instead of the 32 N of the pass pair).  The kernel is the column pass on an
+// R x 256 tile followed by the row pass on the same tile: the tile keeps each row in the row pass's own image (8 chunks of 32
+// elements at stride 36), so the column pass's last write is the row pass's first read.  16 R threads, 16 elements each; in the
+// row pass a half-wave owns a row (two rows one after the other), and only the column/row hand-over needs a workgroup barrier.
+// Plain NTTs only (no epilogue, no gather): everything else keeps the pass pair.
+// ---------------------------------------------------------------------------------------------
+// Read-only tables read through the constant address space: inside a persistent loop (global stores before the next limb's
+// loads) the compiler can no longer prove a plain uniform load unclobbered and would turn it into a vector load; twiddles that go
+// into multiply-adds as scalar operands, the prime constants and the modulus map must stay scalar loads.
+typedef const u64 __attribute__((address_space(4))) *cu64p;
+typedef const u32 __attribute__((address_space(4))) *cu32p;
+__device__ __forceinline__ cu64p as_const(const u64 *p) { return (cu64p)(uintptr_t)p; }
+__device__ __forceinline__ cu32p as_const(const u32 *p) { return (cu32p)(uintptr_t)p; }
+__device__ __forceinline__ PrimeC load_prime_const(const PrimeC *p) {
+  const cu64p q = (cu64p)(uintptr_t)p;
+  PrimeC P;
+  P.p = q[0]; P.twop = q[1]; P.pinv = q[2]; P.r2 = q[3]; P.ninv_m = q[4];
+  const u64 w = q[5];
+  P.p1 = (u32)w; P.pad = (u32)(w >> 32);
+  return P;
+}
+static_assert(sizeof(PrimeC) == 48, "load_prime_const reads six words");
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter (its fence covers global
+// memory), which in the persistent kernels would wait for the prefetched limb and for the row stores at every hand-over.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int LOGR> struct OneCfg {
+  static constexpr int R = 1 << LOGR;
+  static constexpr int LA = LOGR - 4;  // LOGR >= 4
+  static constexpr int LB = 4;
+  static constexpr int T = 16 * R;
+  static constexpr int LDS_WORDS = R * ROW8_LDS;
+};
+__device__ __forceinline__ u32 tile_pos(u32 row, u32 c) { return row * ROW8_LDS + row8_pos(c); }
+
+// Persistent form: workgroup w transforms the limbs w, w + gridDim.x, ... of the nl * batch limbs of the call (limb id = entry * nl
+// + limb).  With a 2^14 limb only one workgroup fits a CU, so nothing else would cover its memory latency: the 16 elements per
+// thread of the NEXT limb are requested in the middle of the current limb's row pass and land while it finishes.  Vector-memory
+// operations retire in issue order, so the order below is the point: twiddles of the second row, then the next limb, then the
+// stores of the first row - every wait then covers only what is needed next.
+template <bool SP, int LOGR>
+__global__ __launch_bounds__(OneCfg<LOGR>::T) void ntt_onepass_fwd_kernel(NttArgs a, u32 nl, u32 total) {
+  using Cfg = OneCfg<LOGR>;
+  constexpr int R = Cfg::R, LA = Cfg::LA, LB = Cfg::LB, T = Cfg::T;
+  __shared__ __attribute__((aligned(16))) u64 lds[Cfg::LDS_WORDS];
+  const u32 tid = threadIdx.x;
+  const u64 N = 1ull << a.logN;
+  const u32 u = tid >> 8, c = tid & 255;
+  u64 pre[16];
+  auto request = [&](u32 id) {
+    const u32 b = __builtin_amdgcn_readfirstlane(id / nl), l = id - b * nl + a.l0;  // wave-uniform (the quotient comes out of the vector unit)
+    const u64 *s = a.src + (u64)b * a.src_bstride + (u64)limb_source(a, l) * N;
+    // element (row g + G k, column cc) of slot tid + rep T sits at tid + 256 (rep T / 256 + G k): one per-thread offset, the rest
+    // is a wave-uniform base (scalar address arithmetic; sixteen per-thread addresses would not fit the register budget)
+    if constexpr (LA > 0) {
+      constexpr int G = R >> LA;
+#pragma unroll
+      for (int rep = 0; rep < (16 >> LA); ++rep) {
+#pragma unroll
+        for (int k = 0; k < (1 << LA); ++k) pre[rep * (1 << LA) + k] = (s + (u64)(rep * (T / 256) + G * k) * 256)[tid];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) pre[k] = (s + (u64)k * 256)[tid];
+    }
+  };
+  u32 id = blockIdx.x;
+  if (id >= total) return;
+  request(id);
+  while (true) {
+    const u32 b = __builtin_amdgcn_readfirstlane(id / nl), l = id - b * nl + a.l0;  // wave-uniform (the quotient comes out of the vector unit)
+    const u32 m = as_const(a.midx)[limb_mod(limb_div(l, a.mdiv, a.mdiv_inv), a.mper, a.mper_inv)];
+    const PrimeC P = load_prime_const(a.primes + m);
+    const u64 *__restrict__ tw = a.tw + (u64)m * N;
+    const cu64p twc = as_const(tw);
+    u64 *d = a.dst + (u64)b * a.dst_bstride + (u64)l * N;
+    {
+      // column pass, stages 0 .. LOGR-1 (as ntt_cols_kernel with a 256-column tile)
+      u64 e[16];
+      if constexpr (LA > 0) {
+        u64 wB[15];
+        load_tw<LB>(wB, tw, (1u << LA) + u);
+        constexpr int G = R >> LA;
+#pragma unroll
+        for (int rep = 0; rep < (16 >> LA); ++rep) {
+          const u32 slot = tid + rep * T, g = slot >> 8, cc = slot & 255;
+          u64 f[1 << LA];
+#pragma unroll
+          for (int k = 0; k < (1 << LA); ++k) { f[k] = pre[rep * (1 << LA) + k]; DBG_RANGE(f[k], 2 * P.twop, 6); }
+          fwd_phase_ua<SP, LA>(f, twc, P);
+#pragma unroll
+          for (int k = 0; k < (1 << LA); ++k) lds[tile_pos(g + G * k, cc)] = f[k];
+        }
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) e[k] = lds[tile_pos((u << LB) + k, c)];
+        fwd_phase_w<SP, LB>(e, wB, P);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { e[k] = pre[k]; DBG_RANGE(e[k], 2 * P.twop, 6); }
+        fwd_phase_ua<SP, LB>(e, twc, P);
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) lds[tile_pos((u << LB) + k, c)] = e[k];
+    }
+    lds_barrier();
+    // row pass, stages LOGR .. logN-1 (as ntt_rows8_fwd_kernel, rows read from the tile): a half-wave owns a row, two rows each.
+    // The thread id goes through an opaque move once per limb: the row pass's ~40 per-thread offsets (twiddle indices, LDS and
+    // store addresses) are the same for every limb, and hoisted out of the loop they would be spilled to scratch and reloaded
+    // between the prefetch loads, each reload draining the memory counter; recomputing them costs ~2 % of a limb's instructions.
+    u32 tid_ = tid;
+    asm volatile("" : "+v"(tid_));
+    const u32 t = tid_ & 31, cq = t >> 2, r = t & 3, p0 = row8_pos(8 * t);
+    const u32 row0 = tid_ >> 5, row1 = row0 + T / 32;
+    u64 wA[7], wB[7], wC0[3], wC1[3];
+    auto row_twiddles = [&](u32 row) {
+      const u32 baseA = (1u << LOGR) + row;
+      load_tw<3>(wA, tw, baseA);
+      load_tw<3>(wB, tw, (baseA << 3) + cq);
+      load_tw<2>(wC0, tw, (baseA << 6) + 2 * t);
+      load_tw<2>(wC1, tw, (baseA << 6) + 2 * t + 1);
+    };
+    auto row_compute = [&](u32 row) {
+      u64 *L = lds + row * ROW8_LDS;
+      u64 e[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e[k] = L[k * 36 + t];
+      fwd_phase_w<SP, 3>(e, wA, P);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) L[k * 36 + t] = e[k];
+      wave_lds_sync();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e[k] = L[cq * 36 + r + 4 * k];
+      fwd_phase_w<SP, 3>(e, wB, P);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) L[cq * 36 + r + 4 * k] = e[k];
+      wave_lds_sync();
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[p0 + k]);
+        e[k] = v.x; e[k + 1] = v.y;
+      }
+      {
+        u64 g0[4] = {e[0], e[1], e[2], e[3]}, g1[4] = {e[4], e[5], e[6], e[7]};
+        fwd_phase_w<SP, 2>(g0, wC0, P);
+        fwd_phase_w<SP, 2>(g1, wC1, P);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { e[k] = canon4(g0[k], P); e[4 + k] = canon4(g1[k], P); }
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) *reinterpret_cast<ulonglong2 *>(&L[p0 + k]) = make_ulonglong2(e[k], e[k + 1]);
+      wave_lds_sync();
+    };
+    auto row_store = [&](u32 row, u32 it) {
+      const u64 *L = lds + row * ROW8_LDS;
+      u64 *dr = d + (u64)it * (T / 32) * 256;  // uniform part of the row address
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32 el = 64 * i + 2 * t;
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[row8_pos(el)]);
+        DBG_RANGE(v.x, P.p, 2); DBG_RANGE(v.y, P.p, 2);
+        *reinterpret_cast<ulonglong2 *>(&dr[row0 * 256 + el]) = v;
+      }
+    };
+    const u32 next = id + gridDim.x;
+    row_twiddles(row0);
+    __builtin_amdgcn_sched_barrier(0);
+    row_compute(row0);
+    __builtin_amdgcn_sched_barrier(0);
+    row_twiddles(row1);
+    __builtin_amdgcn_sched_barrier(0);
+    request(next < total ? next : id);  // the last limb re-requests itself (one code path: the loads stay where they are put)
+    __builtin_amdgcn_sched_barrier(0);
+    row_store(row0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    row_compute(row1);
+    row_store(row1, 1);
+    if (next >= total) break;
+    id = next;
+    lds_barrier();  // the tile is rewritten by the next limb's column pass
+  }
+}
+
+// Inverse: row pass into the tile, then the column pass + N^-1.  Persistent like the forward kernel; the next limb (both rows of
+// every half-wave, 16 elements per thread) is requested at the start of the column pass, behind that pass's own twiddles.
+template <bool SP, int LOGR>
+__global__ __launch_bounds__(OneCfg<LOGR>::T) void ntt_onepass_inv_kernel(NttArgs a, u32 nl, u32 total) {
+  using Cfg = OneCfg<LOGR>;
+  constexpr int R = Cfg::R, LA = Cfg::LA, LB = Cfg::LB, T = Cfg::T;
+  __shared__ __attribute__((aligned(16))) u64 lds[Cfg::LDS_WORDS];
+  const u32 tid = threadIdx.x;
+  const u64 N = 1ull << a.logN;
+  const u32 u = tid >> 8, c = tid & 255;
+  ulonglong2 pre[8];
+  auto request = [&](u32 id) {
+    const u32 b = __builtin_amdgcn_readfirstlane(id / nl), l = id - b * nl + a.l0;  // wave-uniform (the quotient comes out of the vector unit)
+    const u64 *s = a.src + (u64)b * a.src_bstride + (u64)limb_source(a, l) * N;
+    const u32 off = (tid >> 5) * 256 + 2 * (tid & 31);
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pre[4 * it + i] = *reinterpret_cast<const ulonglong2 *>(&(s + (u64)it * (T / 32) * 256 + 64 * i)[off]);
+  };
+  u32 id = blockIdx.x;
+  if (id >= total) return;
+  request(id);
+  while (true) {
+    const u32 b = __builtin_amdgcn_readfirstlane(id / nl), l = id - b * nl + a.l0;
+    const u32 m = as_const(a.midx)[limb_mod(limb_div(l, a.mdiv, a.mdiv_inv), a.mper, a.mper_inv)];
+    const PrimeC P = load_prime_const(a.primes + m);
+    const u64 *__restrict__ tw = a.tw + (u64)m * N;
+    const cu64p twc = as_const(tw);
+    u64 *d = a.dst + (u64)b * a.dst_bstride + (u64)l * N;
+    const u64 nscale = a.inv_scale ? as_const(a.inv_scale)[m] : P.ninv_m;
+    {
+      // row pass, spans 1, 2 | 4, 8, 16 | 32, 64, 128 (as ntt_rows8_inv_kernel), left in the tile.  Opaque thread id: see the forward kernel.
+      u32 tid_ = tid;
+      asm volatile("" : "+v"(tid_));
+      const u32 t = tid_ & 31, cq = t >> 2, r = t & 3, p0 = row8_pos(8 * t);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const u32 row = (tid_ >> 5) + it * (T / 32);
+        u64 *L = lds + row * ROW8_LDS;
+        const u32 baseA = (1u << LOGR) + row;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const ulonglong2 v = pre[4 * it + i];
+          DBG_RANGE(v.x, P.twop, 4); DBG_RANGE(v.y, P.twop, 4);
+          *reinterpret_cast<ulonglong2 *>(&L[row8_pos(64 * i + 2 * t)]) = v;
+        }
+        wave_lds_sync();
+        u64 e[8];
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+          const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L[p0 + k]);
+          e[k] = v.x; e[k + 1] = v.y;
+        }
+        {
+          u64 g0[4] = {e[0], e[1], e[2], e[3]}, g1[4] = {e[4], e[5], e[6], e[7]};
+          inv_phase<SP, 2>(g0, tw, (baseA << 6) + 2 * t, P);
+          inv_phase<SP, 2>(g1, tw, (baseA << 6) + 2 * t + 1, P);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { e[k] = g0[k]; e[4 + k] = g1[k]; }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) *reinterpret_cast<ulonglong2 *>(&L[p0 + k]) = make_ulonglong2(e[k], e[k + 1]);
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = L[cq * 36 + r + 4 * k];
+        inv_phase<SP, 3>(e, tw, (baseA << 3) + cq, P);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) L[cq * 36 + r + 4 * k] = e[k];
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = L[k * 36 + t];
+        inv_phase<SP, 3>(e, tw, baseA, P);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { DBG_RANGE(e[k], P.twop, 5); L[k * 36 + t] = e[k]; }
+      }
+    }
+    lds_barrier();
+    const u32 next = id + gridDim.x;
+    {
+      // column pass (as ntt_cols_kernel<INVERSE> with a 256-column tile) + N^-1; its twiddles first, then the next limb
+      u64 wcol[15];
+      load_tw<LB>(wcol, tw, (1u << LA) + u);
+      __builtin_amdgcn_sched_barrier(0);
+      request(next < total ? next : id);  // the last limb re-requests itself (one code path)
+      __builtin_amdgcn_sched_barrier(0);
+      u64 e[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) e[k] = lds[tile_pos((u << LB) + k, c)];
+      inv_phase_w<SP, LB>(e, wcol, P);
+      if constexpr (LA > 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lds[tile_pos((u << LB) + k, c)] = e[k];
+        lds_barrier();
+        constexpr int G = R >> LA;
+#pragma unroll
+        for (int rep = 0; rep < (16 >> LA); ++rep) {
+          const u32 slot = tid + rep * T, g = slot >> 8, cc = slot & 255;
+          u64 f[1 << LA];
+#pragma unroll
+          for (int k = 0; k < (1 << LA); ++k) f[k] = lds[tile_pos(g + G * k, cc)];
+          inv_phase<SP, LA>(f, twc, 1u, P);
+#pragma unroll
+          for (int k = 0; k < (1 << LA); ++k) {
+            const u64 v = csub(mont_mul<SP>(nscale, f[k], P), P.p);
+            DBG_RANGE(v, P.p, 9);
+            (d + (u64)(rep * (T / 256) + G * k) * 256)[tid] = v;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const u64 v = csub(mont_mul<SP>(nscale, e[k], P), P.p); DBG_RANGE(v, P.p, 9); (d + (u64)k * 256)[tid] = v; }
+      }
+    }
+    if (next >= total) break;
+    id = next;
+    lds_barrier();  // the tile is rewritten by the next limb's row pass
   }
 }

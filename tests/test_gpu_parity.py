@@ -544,6 +544,33 @@ def test_relinearisation_in_groups_of_output_limbs(logN, L, Li, group):
         g.set_tuning(99, 1)
 
 
+@pytest.mark.parametrize("logN", [12, 13, 14])
+@pytest.mark.parametrize("generic", [False, True])
+def test_one_pass_ntt_matches_the_pass_pair_and_the_oracle(logN, generic):
+    """N = 2^12 .. 2^14: plain NTTs run as one kernel with the limb in LDS (ntt_onepass_*); FHE_HIP_TUNE_ONEPASS = 0 selects the
+    column/row pass pair.  Both must give the oracle's words: forward from lazy inputs (< 4p), in place and broadcast
+    (one source limb under several primes), inverse, batch > 1, and a limb list with repeats."""
+    o, g = ctx_pair(logN, 3, 1, sp=not generic)
+    idx = [3, 0, 2, 2, 1]
+    x = rand_poly(o, idx, 3000 + logN)
+    want_f = o.ntt_forward(x.copy(), idx)
+    lazy = x + np.array([3 * int(o.primes[i]) for i in idx], dtype=np.uint64)[:, None]   # same residues, values in [3p, 4p)
+    xs = np.stack([rand_poly(o, range(3), 3100 + logN + b) for b in range(3)])
+    want_r = np.stack([o.rescale(xs[b]) for b in range(3)])
+    try:
+        for mode in (1, 0):
+            g.set_tuning(fhe_amd.hip.TUNE_ONEPASS, mode)
+            d = dev(lazy); g.ntt_forward(d, idx)
+            assert np.array_equal(host(d), want_f), mode
+            g.ntt_backward(d, idx)
+            assert np.array_equal(host(d), x), mode
+            rop = torch.zeros((3, 2, o.N), dtype=torch.int64, device="cuda")
+            g.rescale(rop, dev(xs), 3, batch=3)     # inverse of one limb + broadcast forward with an epilogue (pass pair) per entry
+            assert np.array_equal(host(rop), want_r), mode
+    finally:
+        g.set_tuning(fhe_amd.hip.TUNE_ONEPASS, 1)
+
+
 # ---- full-size results pinned by mathematics, not only by the oracle (VERDICT r1 item 6) ----
 @pytest.mark.parametrize("logN", [14, 15, 16])
 def test_full_size_forward_ntt_against_horner_in_python_integers(logN):
