@@ -123,8 +123,8 @@ def dominant_kernel_bytes(workload, N, Li, K, units_per_launch):
         shared = 8 * N * (2 * Li * Li + units_per_launch * (Li * Li + 4 * Li))
         per_op = 8 * N * units_per_launch * (2 * Li * Li + Li * Li + 4 * Li)
         return shared, per_op
-    if workload == "c4":    # the three base conversions of a rotation: Li (or K) limbs in, K (or Li) limbs out each
-        b = units_per_launch * 8 * N * (Li + K)
+    if workload == "c4":    # mod-down of both halves of a rotation in one launch: 2 x (K special limbs in, Li normal limbs out)
+        b = units_per_launch * 2 * 8 * N * (Li + K)
         return b, b
     b = units_per_launch * 16 * N  # ntt / c2: the cols + rows pair is one limb-NTT = read N + write N words
     return b, b
@@ -387,9 +387,8 @@ class Setup:
             kname = "whole pipeline: " + " + ".join(sorted(prof))
             units_per_launch = B
         elif w == "c4":
-            launches = kms("bconv_modup")[0] + kms("bconv_moddown")[0]
-            ms = kms("bconv_modup")[1] + kms("bconv_moddown")[1]
-            kname = "bconv_kernel (mod-up + 2x mod-down)"
+            launches, ms = kms("bconv_moddown")   # the larger of the two conversion launches: both halves' mod-down in one
+            kname = "bconv_kernel (mod-down of both halves, one launch)"
             units_per_launch = B
         elif kms("ntt_fwd_onepass")[0]:  # N <= 2^14: the limb stays in one workgroup's LDS, one kernel per transform
             launches, ms = kms("ntt_fwd_onepass")

@@ -1,25 +1,25 @@
 #!/usr/bin/env python3
-"""Copy the outputs of tools/gpu_final_refresh.sh <tag> (merged under gpurun_out/) into profiles/r01 and profiles/traffic_*.json,
-and print the results table rows for BASELINE.md.  usage: tools/collect_profiles.py <tag>"""
-import glob, json, os, shutil, subprocess, sys
-tag = sys.argv[1]
+"""Copy the outputs of tools/gpu_final_refresh.sh <tag> (merged under gpurun_out/<tag>) into profiles/<round> and
+profiles/{traffic,valu}_*.json, and print one summary row per workload.  usage: tools/collect_profiles.py <tag> <round>"""
+import glob, json, os, shutil, sys
+tag, rnd = sys.argv[1], sys.argv[2]
 src = os.path.join("gpurun_out", tag)
-dst = os.path.join("profiles", "r01")
+dst = os.path.join("profiles", rnd)
+os.makedirs(dst, exist_ok=True)
 for wl in ("c3", "ntt", "c4"):
-    stats = sorted(glob.glob(os.path.join(src, "stats_%s" % wl, "*", "*kernel_stats.csv")), key=os.path.getsize)[-1]
-    shutil.copy(stats, os.path.join(dst, "%s_kernel_stats.csv" % wl))
+    shutil.copy(os.path.join(src, "%s_kernel_stats.csv" % wl), os.path.join(dst, "%s_kernel_stats.csv" % wl))
     shutil.copy(os.path.join(src, "pmc_summary_%s.txt" % wl), os.path.join(dst, "%s_pmc_fetch_write.txt" % wl))
-    t = json.load(open(os.path.join(src, "traffic_%s.json" % wl)))
-    t["source"] = "profiles/r01/%s_pmc_fetch_write.txt" % wl
-    json.dump(t, open(os.path.join("profiles", "traffic_%s.json" % wl), "w"), indent=1)
-for wl in ("c2", "c3", "c4", "c5", "ntt", "rotm", "rotnn", "dec", "enc"):
-    shutil.copy(os.path.join(src, "bench_%s.json" % wl), os.path.join(dst, "bench_%s.json" % wl))
-for wl in ("c3", "ntt"):
-    out = subprocess.run([sys.executable, "tools/pmc_summary.py", os.path.join("gpurun_out", "%s_pmc_%s" % (tag, wl))], capture_output=True, text=True).stdout
-    open(os.path.join(dst, "%s_pmc_sq_valu.txt" % wl), "w").write(out)
-for wl in ("c3", "ntt", "c4", "c5", "c2", "rotm", "rotnn", "dec", "enc"):
-    r = json.load(open(os.path.join(dst, "bench_%s.json" % wl)))
-    rf, cb = r["roofline"], r["cpu_baseline"]
-    print("%-6s %10.1f %-12s whole %.3f  kernel %6.0f GB/s (%.3f)  traffic %s  alg/launch %.3e  cpu %.2f / %.1f" % (
-        wl, r["value"], r["unit"], r["roofline_whole_op"]["frac_of_hbm_peak"], rf["achieved"], rf["frac"], rf.get("traffic"),
-        rf["alg_bytes_per_launch"], cb["value"], cb["all_cores"]["value"]))
+    shutil.copy(os.path.join(src, "pmc_valu_summary_%s.txt" % wl), os.path.join(dst, "%s_pmc_sq_valu.txt" % wl))
+    for kind in ("traffic", "valu"):
+        t = json.load(open(os.path.join(src, "%s_%s.json" % (kind, wl))))
+        t["source"] = "profiles/%s/%s_pmc_%s.txt" % (rnd, wl, "fetch_write" if kind == "traffic" else "sq_valu")
+        json.dump(t, open(os.path.join("profiles", "%s_%s.json" % (kind, wl)), "w"), indent=1)
+for f in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
+    shutil.copy(f, os.path.join(dst, os.path.basename(f)))
+    r = json.load(open(f))
+    rf = r.get("roofline") or {}
+    rv = r.get("roofline_valu") or {}
+    cb = r.get("cpu_baseline") or {}
+    print("%-22s %12.1f %-12s whole %.3f  kernel %6.0f GB/s (%.3f)  valu %.2f  cpu %s / %s" % (
+        os.path.basename(f)[6:-5], r["value"], r["unit"], r["roofline_whole_op"]["frac_of_hbm_peak"], rf.get("achieved", 0), rf.get("frac", 0),
+        rv.get("frac", 0), cb.get("value"), (cb.get("all_cores") or {}).get("value")))

@@ -28,8 +28,8 @@ for wl in $WLS; do
         python3 $M/make_valu_json.py $OUT/valu_c3 c3 "c3, default batch per launch, N=2^16 Li=30" $OUT/valu_c3.json relin_rows8p ;;
     ntt) python3 $M/make_traffic_json.py $OUT/pmc_summary_ntt.txt ntt "ntt, 2048 limbs/launch, N=2^16" $OUT/traffic_ntt.json "ntt_cols_kernel<true, false" "ntt_rows8_fwd_kernel<true, 0"
         python3 $M/make_valu_json.py $OUT/valu_ntt ntt "ntt, 2048 limbs/launch, N=2^16" $OUT/valu_ntt.json "ntt_cols_kernel<true, false" "ntt_rows8_fwd_kernel<true, 0" ;;
-    c4) python3 $M/make_traffic_json.py $OUT/pmc_summary_c4.txt c4 "c4, default batch per launch, N=2^16 Li=K=30 (one base-conversion launch)" $OUT/traffic_c4.json bconv_kernel
-        python3 $M/make_valu_json.py $OUT/valu_c4 c4 "c4, default batch per launch, N=2^16 Li=K=30 (one base-conversion launch)" $OUT/valu_c4.json bconv_kernel ;;
+    c4) python3 $M/make_traffic_json.py $OUT/pmc_summary_c4.txt c4 "c4, default batch per launch, N=2^16 Li=K=30 (mod-down launch: both halves)" $OUT/traffic_c4.json bconv_kernel
+        python3 $M/make_valu_json.py $OUT/valu_c4 c4 "c4, default batch per launch, N=2^16 Li=K=30 (mod-down launch: both halves)" $OUT/valu_c4.json bconv_kernel ;;
   esac
 done
 # raw counter dumps are large: keep the summaries and the JSONs
