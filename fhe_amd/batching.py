@@ -27,6 +27,13 @@ class ShardedBatch:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.device = device
+        # gloo moves host memory only: device tensors are staged through host copies there (CPU tests, and rehearsals of the
+        # multi-rank logic on a box without RCCL peers); with nccl (= RCCL) the device buffers go on the wire as they are
+        self.stage = dist.is_initialized() and dist.get_backend(group) == "gloo"
+
+    def _wire(self, t):
+        """The tensor a point-to-point operation is posted with."""
+        return t.cpu() if (self.stage and t.is_cuda) else t
 
     def bounds(self, n_items, rank=None):
         return shard_bounds(n_items, self.world, self.rank if rank is None else rank)
@@ -37,7 +44,18 @@ class ShardedBatch:
     @staticmethod
     def _p2p_wait(reqs):
         for req in reqs:
-            req.wait()  # RCCL: the current stream waits, the host does not
+            if callable(req):
+                req()       # staged receive: copy the host buffer into its device destination
+            else:
+                req.wait()  # RCCL: the current stream waits, the host does not
+
+    def _recv_op(self, dst, peer, post):
+        """irecv into dst (staged through the host under gloo); `post` collects the copies to run after the wait."""
+        if self.stage and dst.is_cuda:
+            host = torch.empty(dst.shape, dtype=dst.dtype)
+            post.append(lambda: dst.copy_(host))
+            return dist.P2POp(dist.irecv, host, peer, self.group)
+        return dist.P2POp(dist.irecv, dst, peer, self.group)
 
     def _p2p(self, ops):
         self._p2p_wait(self._p2p_start(ops))
@@ -55,12 +73,13 @@ class ShardedBatch:
                     continue
                 rlo, rhi = self.bounds(n_items, r)
                 if rhi > rlo:
-                    keep.append(full[rlo:rhi].contiguous())
+                    keep.append(self._wire(full[rlo:rhi].contiguous()))
                     ops.append(dist.P2POp(dist.isend, keep[-1], r, self.group))
             return full[lo:hi], self._p2p_start(ops), keep
         local = torch.empty((hi - lo,) + tuple(item_shape), dtype=dtype, device=self.device)
-        reqs = self._p2p_start([dist.P2POp(dist.irecv, local, self.root, self.group)]) if hi > lo else []
-        return local, reqs, None
+        post = []
+        reqs = self._p2p_start([self._recv_op(local, self.root, post)]) if hi > lo else []
+        return local, list(reqs) + post, None
 
     def scatter(self, full, n_items, item_shape, dtype=torch.int64):
         """Root holds `full` = [n_items, *item_shape]; every rank returns its slice [hi-lo, *item_shape]."""
@@ -76,23 +95,28 @@ class ShardedBatch:
         if self.rank == self.root:
             full = torch.empty((n_items,) + tuple(item_shape), dtype=dtype, device=self.device)
             full[lo:hi] = local
-            ops = []
+            ops, post = [], []
             for r in range(self.world):
                 if r == self.root:
                     continue
                 rlo, rhi = self.bounds(n_items, r)
                 if rhi > rlo:
-                    ops.append(dist.P2POp(dist.irecv, full[rlo:rhi], r, self.group))
-            self._p2p(ops)
+                    ops.append(self._recv_op(full[rlo:rhi], r, post))
+            self._p2p_wait(list(self._p2p_start(ops)) + post)
             return full
         if hi > lo:
-            self._p2p([dist.P2POp(dist.isend, local.contiguous(), self.root, self.group)])
+            self._p2p([dist.P2POp(dist.isend, self._wire(local.contiguous()), self.root, self.group)])
         return None
 
     def broadcast(self, tensor):
         """Key material: once, from the root to every rank."""
         if self.world > 1:
-            dist.broadcast(tensor, self.root, group=self.group)
+            if self.stage and tensor.is_cuda:
+                host = tensor.cpu()
+                dist.broadcast(host, self.root, group=self.group)
+                tensor.copy_(host)
+            else:
+                dist.broadcast(tensor, self.root, group=self.group)
         return tensor
 
     def run(self, compute, inputs, n_items, in_shapes, out_shape, chunk=None):
