@@ -92,3 +92,43 @@ def test_noalloc_rejects_what_does_not_fit_and_host_buffers():
         g.mul_relin_rescale_noalloc(np.zeros((1, 2, Li - 1, N), np.uint64), np.zeros((1, 2, Li, N), np.uint64),
                                     np.zeros((1, 2, Li, N), np.uint64), Li, batch=1)
     g.close()
+
+
+def test_noalloc_entry_point_can_be_captured_in_a_hip_graph_and_replayed():
+    """What the entry point is for: a caller under stream capture.  The call is captured on a side stream (nothing executes, no
+    allocation, event or synchronisation is attempted inside it), and replays give the allocating entry point's bits, also
+    after the input buffers' contents changed."""
+    logN, L, K, Li, B = 13, 4, 1, 4, 2
+    pr, ps = orc.gen_primes(logN, L + K)
+    g = fhe_amd.HipContext(logN, L, K, pr, ps)
+    N = 1 << logN
+    gen = torch.Generator(device="cuda").manual_seed(78)
+    g.load_mult_key(_rand((L, L, N), gen), _rand((L, L, N), gen))
+    c0, c1 = _rand((B, 2, Li, N), gen), _rand((B, 2, Li, N), gen)
+    want = torch.zeros((B, 2, Li - 1, N), dtype=torch.int64, device="cuda")
+    out = torch.zeros_like(want)
+    g.mul_relin_rescale(want, c0, c1, Li, batch=B)
+    g.mul_relin_rescale_noalloc(out, c0, c1, Li, batch=B)  # first call outside the capture
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    out.zero_()
+    side, graph = torch.cuda.Stream(), torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.stream(side):
+            g.set_stream(side.cuda_stream)
+            with torch.cuda.graph(graph, stream=side):
+                g.mul_relin_rescale_noalloc(out, c0, c1, Li, batch=B)
+    finally:
+        g.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert not bool(out.any()), "a captured call must not run"
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    c0.copy_(_rand((B, 2, Li, N), gen))
+    g.mul_relin_rescale(want, c0, c1, Li, batch=B)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    del graph
+    g.close()
