@@ -574,7 +574,7 @@ int dev_rotate_to(fhe_hip_ctx *c, u64 galois, u64 *out, const u64 *in, u32 Li, u
   RotSpArgs ra;
   ra.e0 = E; ra.e1 = E + (size_t)K * N; ra.estride = (u64)2 * K * N; ra.beta_m = it->second.beta_m; ra.alpha_m = it->second.alpha_m;
   ra.tw_fwd = c->d_tw_fwd; ra.tw_inv = c->d_tw_inv; ra.primes = c->d_primes;
-  ra.first_mod = c->L; ra.first_limb = 0; ra.logN = c->logN; ra.logR = c->logR;
+  ra.first_mod = c->L; ra.mmap = nullptr; ra.first_limb = 0; ra.logN = c->logN; ra.logR = c->logR;
   const u32 R = 1u << c->logR, rows = R < 8 ? R : 8;
   LAUNCH_SP(c, "rot_special_rows", rot_special_rows8_kernel, dim3(R / rows, K, batch), dim3(32 * rows), ra);
   // from here on the two halves are 2*batch entries of K special limbs: column pass of their inverse NTTs (output = mod-down digits)
@@ -598,39 +598,47 @@ int dev_rotate_non_ntt(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch) {
   const u64 N = c->N; const u32 K = c->K, nl = Li + K;
   auto it = c->rot_keys.find(galois);
   if (it == c->rot_keys.end()) FAIL(c, FHE_HIP_ERR_NOKEY, "rotation key not loaded for this galois element");
-  const size_t ctb = (size_t)batch * 2 * Li * N * 8, extb = (size_t)batch * nl * N * 8;
-  TRY(ensure_ws(c, 3, ctb));       // g = galois(ct): [b][2][Li][N]
-  TRY(ensure_ws(c, 4, extb));      // ext / e0
-  TRY(ensure_ws(c, 5, extb));      // e1
-  u64 *g = (u64 *)c->ws[3], *e0 = (u64 *)c->ws[4], *e1 = (u64 *)c->ws[5];
+  const size_t ctb = (size_t)batch * 2 * Li * N * 8;
+  TRY(ensure_ws(c, 3, ctb));                                   // g = galois(ct): [b][2][Li][N]
+  TRY(ensure_ws(c, 4, (size_t)batch * 2 * nl * N * 8));        // E[b][2][Li+K][N]: the extended polynomial, then both key products
+  TRY(ensure_ws(c, 2, (size_t)batch * 2 * Li * N * 8));        // conversions back to the normal basis, both halves
+  u64 *g = (u64 *)c->ws[3], *E = (u64 *)c->ws[4], *conv = (u64 *)c->ws[2];
   if (galois == 1) {
     HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(g, ct, ctb, hipMemcpyDeviceToDevice, c->stream)));
   } else {
     LAUNCH(c, "galois_coeff", galois_coeff_kernel, dim3((unsigned)(N / PW_THREADS), 2 * Li, batch), dim3(PW_THREADS), g, (const u64 *)ct,
            (const PrimeC *)c->d_primes, c->logN, galois_inverse(galois, c->N), Li);
   }
-  // ax_g is already in the power basis (:537): mod up, then forward NTT of all Li+K limbs (:539-542)
-  TRY(dev_conv_to_special(c, e0, nl, Li, g + (size_t)Li * N, 2 * Li, Li, batch));
-  for (u32 b = 0; b < batch; ++b)
-    HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(e0 + (size_t)b * nl * N, g + ((size_t)b * 2 + 1) * Li * N, (size_t)Li * N * 8, hipMemcpyDeviceToDevice, c->stream)));
+  // ax_g is already in the power basis (:537): mod up into the special limbs of E[b][0], then the forward NTT of all Li+K limbs
+  // (:539-542): the column pass reads the normal limbs from g where they lie (no copy into E) and the special limbs in place
+  TRY(dev_conv_to_special(c, E, 2 * nl, Li, g + (size_t)Li * N, 2 * Li, Li, batch));
   const u32 *rotmap = c->d_rotmap + (size_t)Li * c->M;
-  NttPlan pf{e0, e0, rotmap, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
-  TRY(ntt_run(c, pf, false));
-  // key product over all Li+K limbs, then every limb back to the power basis (:544-567)
-  LAUNCH_SP(c, "rot_keymul", rot_keymul_kernel, pw_grid(c, nl, batch), dim3(PW_THREADS), e0, e1, (const u64 *)e0, (const u64 *)it->second.beta_m,
-            (const u64 *)it->second.alpha_m, (const PrimeC *)c->d_primes, rotmap, nl, N);
-  NttPlan p0{e0, e0, rotmap, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
-  TRY(ntt_run(c, p0, true));
-  NttPlan p1{e1, e1, rotmap, 1, nl, nl, nl, batch, (u64)nl * N, (u64)nl * N};
-  TRY(ntt_run(c, p1, true));
-  // mod down both halves straight into ct (strided [b][2][Li][N]); rop[0] += galois(bx) read from g (:568-572)
-  TRY(ensure_ws(c, 2, (size_t)batch * Li * N * 8));
-  u64 *conv = (u64 *)c->ws[2];
+  NttPlan pn{g + (size_t)Li * N, E, rotmap, 1, nl, Li, Li, batch, (u64)2 * Li * N, (u64)2 * nl * N};
+  pn.cols_only = true;
+  TRY(ntt_run(c, pn, false));
+  if (K) {
+    NttPlan ps{E, E, rotmap, 1, nl, nl, K, batch, (u64)2 * nl * N, (u64)2 * nl * N};
+    ps.cols_only = true; ps.l0 = Li;
+    TRY(ntt_run(c, ps, false));
+  }
+  // forward row pass, key product over all Li+K limbs (:544-556) and the row pass of both inverse NTTs (:557-567) on the same rows
+  RotSpArgs ra;
+  ra.e0 = E; ra.e1 = E + (size_t)nl * N; ra.estride = (u64)2 * nl * N; ra.beta_m = it->second.beta_m; ra.alpha_m = it->second.alpha_m;
+  ra.tw_fwd = c->d_tw_fwd; ra.tw_inv = c->d_tw_inv; ra.primes = c->d_primes;
+  ra.first_mod = 0; ra.mmap = rotmap; ra.first_limb = 0; ra.logN = c->logN; ra.logR = c->logR;
+  const u32 R = 1u << c->logR, rows = R < 8 ? R : 8;
+  LAUNCH_SP(c, "rot_special_rows", rot_special_rows8_kernel, dim3(R / rows, nl, batch), dim3(32 * rows), ra);
+  // the two halves are now 2*batch entries of Li+K limbs: column pass of their inverse NTTs
+  NttPlan pc{E, E, rotmap, 1, nl, nl, nl, 2 * batch, (u64)nl * N, (u64)nl * N};
+  pc.cols_only = true;
+  TRY(ntt_run(c, pc, true));
+  // mod down both halves (one conversion launch) straight into ct (strided [b][2][Li][N]); rop[0] += galois(bx) read from g (:568-572)
+  if (K) TRY(dev_conv_to_normal(c, conv, Li, E, nl, Li, 2 * batch, false));
+  else HIPCHK(c, (prof_chain_break(c), hipMemsetAsync(conv, 0, (size_t)batch * 2 * Li * N * 8, c->stream)));
   for (int h = 0; h < 2; ++h) {
-    const u64 *op = h == 0 ? e0 : e1;
-    TRY(dev_conv_to_normal(c, conv, Li, op, nl, Li, batch, false));
-    NttPlan p{conv, conv, c->d_iota, 1, Li, Li, Li, batch, (u64)Li * N, (u64)Li * N};
-    p.epi = 2; p.epi_src = op; p.epi_src_bstride = (u64)nl * N; p.epi_c = c->d_Pinv_qj_m;
+    u64 *cv = conv + (size_t)h * Li * N;
+    NttPlan p{cv, cv, c->d_iota, 1, Li, Li, Li, batch, (u64)2 * Li * N, (u64)2 * Li * N};
+    p.epi = 2; p.epi_src = E + (size_t)h * nl * N; p.epi_src_bstride = (u64)2 * nl * N; p.epi_c = c->d_Pinv_qj_m;
     p.epi_add = h == 0 ? g : nullptr; p.epi_add_bstride = (u64)2 * Li * N;
     p.epi_out = ct + (size_t)h * Li * N; p.epi_out_bstride = (u64)2 * Li * N;
     TRY(ntt_run(c, p, false));

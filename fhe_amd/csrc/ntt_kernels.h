@@ -373,6 +373,7 @@ struct RotSpArgs {
   const u64 *tw_fwd, *tw_inv;
   const PrimeC *primes;
   u32 first_mod;                 // modulus index of the first special limb (= L)
+  const u32 *mmap;               // optional: limb -> modulus index (all Li + K limbs of the power-basis rotation); null = first_mod + limb
   u32 first_limb;                // its limb position inside an entry
   u32 logN, logR;
 };
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(256) void rot_special_rows8_kernel(RotSpArgs a) {
   __shared__ __attribute__((aligned(16))) u64 lds[8 * ROW8_LDS];
   const u32 tid = threadIdx.x, rloc = tid >> 5, t = tid & 31;
   const u32 row = blockIdx.x * (blockDim.x >> 5) + rloc;  // 8 rows per workgroup (R < 8: all R rows, 32 * R threads)
-  const u32 m = a.first_mod + blockIdx.y, b = blockIdx.z;
+  const u32 m = a.mmap ? a.mmap[blockIdx.y] : a.first_mod + blockIdx.y, b = blockIdx.z;
   const PrimeC P = a.primes[m];
   const u64 N = 1ull << a.logN;
   const u64 *__restrict__ twf = a.tw_fwd + (u64)m * N;
