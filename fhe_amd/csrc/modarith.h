@@ -31,7 +31,7 @@ __device__ __forceinline__ u64 mad_wide(u32 a, u32 b, u64 c) { return (u64)a * (
 // site remembered), never trapped: a trapping kernel faults the GPU.  fhe_hip_debug_violations() reads the counters.
 // Sites: 1 fwd rows in (<4p), 2 fwd rows out (<p), 3 fwd rows epilogue out (<p), 4 inv rows in (<2p), 5 inv rows out (<2p),
 // 6 fwd cols in (<4p), 7 fwd cols out (<4p), 8 inv cols in (<2p), 9 inv cols out (<p), 10 relin out (<p), 11 relin digit in (<4p),
-// 12 rotation special-limb rows out (<2p), 13 bconv out (<p), 14 cross_mult out (<p), 15 key product out (<p), 16 pointwise out (<p).
+// 12 rotation special-limb rows out (<2p), 13 bconv out (<p), 14 cross_mult out (<p), 15 (unused since the key products moved into the row passes), 16 pointwise out (<p).
 #ifdef FHE_HIP_DEBUG
 __device__ unsigned long long fhe_hip_dbg_count = 0;
 __device__ unsigned int fhe_hip_dbg_first_site = 0;

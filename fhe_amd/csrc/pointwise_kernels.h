@@ -159,23 +159,6 @@ __global__ __launch_bounds__(PW_THREADS) void bconv_kernel(BconvArgs a) {
   }
 }
 
-// key multiply of apply_rotation_key_non_ntt (src/evaluator.cpp:544-556): e0 = ext * beta[idx], e1 = ext * alpha[idx],
-// idx = midx[cm] (cm < Li ? cm : L + cm - Li).  ext/e0/e1 = [b][nl][N]; keys [L+K][N] Montgomery form.  (The NTT-domain
-// rotation forms its key products inside rot_special_rows8_kernel and the mod-down tail, NttArgs::epi == 4.)
-template <bool SP>
-__global__ __launch_bounds__(PW_THREADS) void rot_keymul_kernel(u64 *e0, u64 *e1, const u64 *ext, const u64 *beta_m,
-                                                                const u64 *alpha_m, const PrimeC *primes, const u32 *midx, u32 nl, u64 N) {
-  const u64 d = ((u64)blockIdx.x * PW_THREADS + threadIdx.x) * 2;
-  const u32 cm = blockIdx.y, b = blockIdx.z;
-  const u32 m = midx[cm];
-  const PrimeC P = primes[m];
-  const u64 o = ((u64)b * nl + cm) * N + d;
-  const ulonglong2 x = ld2(ext + o);
-  const ulonglong2 kb = ld2(beta_m + (u64)m * N + d), ka = ld2(alpha_m + (u64)m * N + d);
-  st2c(e0 + o, csub(mont_mul<SP>(kb.x, x.x, P), P.p), csub(mont_mul<SP>(kb.y, x.y, P), P.p), P.p, 15);
-  st2c(e1 + o, csub(mont_mul<SP>(ka.x, x.x, P), P.p), csub(mont_mul<SP>(ka.y, x.y, P), P.p), P.p, 15);
-}
-
 // fHE::apply_galois (src/yell.cpp:14-24) as a gather through a per-galois index table; out-of-place.
 __global__ __launch_bounds__(PW_THREADS) void galois_gather_kernel(u64 *dst, const u64 *src, const u32 *perm, u64 N, u64 src_bstride,
                                                                    u64 dst_bstride) {
