@@ -11,6 +11,7 @@
 // Inverse = row pass then column pass (+ N^-1).  Column pass: every thread keeps 16 elements in registers for
 // 4 stages (radix-16), exchanging through LDS once; row pass: 8 elements per thread, register phases of 3 + 3 + 2
 // stages.  Values stay lazy ([0,4p) forward, [0,2p) inverse) and are made canonical only by the last pass.
+// For N <= 2^14 a limb fits one workgroup's LDS and plain transforms run as ONE kernel (ntt_onepass_*, end of this file).
 #pragma once
 #include "modarith.h"
 
