@@ -652,3 +652,60 @@ def test_rotate_out_of_place_matches_in_place_and_oracle(logN, L, K, Li):
     with pytest.raises(fhe_amd.FheHipError) as e:
         g.rotate_to(3, src, src, Li, batch=B)
     assert e.value.code == -1
+
+
+def test_full_size_rotation_and_multiplication_decrypt_to_the_right_plaintext():
+    """N = 2^16, pinned by what the operations MEAN rather than by a second implementation: an encryption of m rotated on the GPU
+    decrypts (on the GPU) to m(X^g) up to key-switch noise, and the product of two encryptions decrypts to the negacyclic
+    product / q_last up to relinearisation + rescale noise.  Plaintext coefficients are lifted by CRT in Python integers at
+    sampled positions; keys and fresh encryptions come from the definitions in the CPU restatement (keygen / encrypt only)."""
+    logN, L, K = 16, 4, 4
+    o, g = ctx_pair(logN, L, K)
+    N = o.N
+    q = [int(v) for v in o.primes[:L]]
+    sx, ext = o.keygen_sk(seed=41)
+    pkb, pka = o.keygen_pk(sx, seed=42)
+    gal = o.rotation_galois(1)
+    rkb, rka = o.keygen_rot(sx, ext, gal, seed=43)
+    beta, alpha = o.keygen_mult(sx, seed=44)
+    g.load_rot_key(gal, dev(rkb), dev(rka))
+    g.load_mult_key(dev(beta), dev(alpha))
+    rng = np.random.default_rng(9)
+    sa, sb = rng.integers(-8, 9, N), rng.integers(-8, 9, N)
+
+    def encode(small, shift):
+        return np.stack([np.array([(int(v) << shift) % p for v in small], dtype=np.uint64) for p in q])
+
+    def lifted(limbs, mods, d):
+        Q = 1
+        for m in mods:
+            Q *= m
+        x = sum(int(limbs[j, d]) * pow(Q // m, -1, m) % m * (Q // m) for j, m in enumerate(mods)) % Q
+        return x - Q if x > Q // 2 else x
+
+    def gpu_decrypt(ct, Li):
+        out = torch.zeros((1, Li, N), dtype=torch.int64, device="cuda")
+        g.decrypt(out, ct, dev(sx), Li, batch=1)
+        return host(out)[0]
+
+    pos = [0, 1, N - 1, N // 2] + [int(v) for v in rng.integers(0, N, 12)]
+    # rotation: coefficient d of m lands on d*g mod 2N, negated when it wraps past N
+    ca = np.stack(o.encrypt(encode(sa, 50), pkb, pka, seed=45))
+    rot = torch.zeros((1, 2, L, N), dtype=torch.int64, device="cuda")
+    g.rotate_to(gal, rot, dev(ca[None]), L, batch=1)
+    dec = gpu_decrypt(rot, L)
+    for d in pos:
+        e = d * gal % (2 * N)
+        want, at = ((int(sa[d]) << 50), e) if e < N else (-(int(sa[d]) << 50), e - N)
+        assert abs(lifted(dec, q, at) - want) < 1 << 24, d
+    # multiplication: (a * b mod X^N + 1) / q_last
+    c0 = np.stack(o.encrypt(encode(sa, 40), pkb, pka, seed=47))
+    c1 = np.stack(o.encrypt(encode(sb, 40), pkb, pka, seed=46))
+    out = torch.zeros((1, 2, L - 1, N), dtype=torch.int64, device="cuda")
+    g.mul_relin_rescale(out, dev(c0[None]), dev(c1[None]), L, batch=1)
+    dec = gpu_decrypt(out, L - 1)
+    idx = np.arange(N)
+    for e in pos:
+        sign = np.where(idx <= e, 1, -1)
+        coef = int(np.sum(sa.astype(np.int64) * sb[(e - idx) % N].astype(np.int64) * sign)) << 80
+        assert abs(lifted(dec, q[:L - 1], e) * q[L - 1] - coef) < 1 << 80, e
