@@ -698,6 +698,16 @@ def test_full_size_rotation_and_multiplication_decrypt_to_the_right_plaintext():
         e = d * gal % (2 * N)
         want, at = ((int(sa[d]) << 50), e) if e < N else (-(int(sa[d]) << 50), e - N)
         assert abs(lifted(dec, q, at) - want) < 1 << 24, d
+    # the same rotation through the MixedRotKey key switch (digit decomposition + one special prime)
+    mb, ma = o.keygen_mixed_rot(sx, ext, gal, seed=48)
+    g.load_mixed_rot_key(gal, dev(mb), dev(ma))
+    rot = dev(ca[None].copy())
+    g.rotate_mixed(gal, rot, L, batch=1)
+    dec = gpu_decrypt(rot, L)
+    for d in pos:
+        e = d * gal % (2 * N)
+        want, at = ((int(sa[d]) << 50), e) if e < N else (-(int(sa[d]) << 50), e - N)
+        assert abs(lifted(dec, q, at) - want) < 1 << 24, d
     # multiplication: (a * b mod X^N + 1) / q_last
     c0 = np.stack(o.encrypt(encode(sa, 40), pkb, pka, seed=47))
     c1 = np.stack(o.encrypt(encode(sb, 40), pkb, pka, seed=46))
