@@ -6,7 +6,7 @@ tag, rnd = sys.argv[1], sys.argv[2]
 src = os.path.join("gpurun_out", tag)
 dst = os.path.join("profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-for wl in ("c3", "ntt", "c4"):
+for wl in [w for w in ("c3", "ntt", "c4", "c2") if os.path.exists(os.path.join(src, "%s_kernel_stats.csv" % w))]:
     shutil.copy(os.path.join(src, "%s_kernel_stats.csv" % wl), os.path.join(dst, "%s_kernel_stats.csv" % wl))
     shutil.copy(os.path.join(src, "pmc_summary_%s.txt" % wl), os.path.join(dst, "%s_pmc_fetch_write.txt" % wl))
     shutil.copy(os.path.join(src, "pmc_valu_summary_%s.txt" % wl), os.path.join(dst, "%s_pmc_sq_valu.txt" % wl))

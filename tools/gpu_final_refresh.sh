@@ -1,11 +1,11 @@
 #!/bin/bash
 # Everything profiles/<round> holds, from the current tree: tools/gpu_final_refresh.sh <tag>   (then tools/collect_profiles.py <tag> <round>)
-# 1. rocprofv3 kernel stats + FETCH / WRITE / VALU counter passes for c3, ntt, c4 (tools/gpu_profile_round.sh)
+# 1. rocprofv3 kernel stats + FETCH / WRITE / VALU counter passes for c3, ntt, c4, c2 (tools/gpu_profile_round.sh)
 # 2. the driver's default line (c3 + ntt_n16 + cpu_baseline) and one bench line per other workload
 set -o pipefail
 TAG=${1:-final}
 mkdir -p gpurun_out/$TAG
-bash tools/gpu_profile_round.sh $TAG c3 ntt c4 > gpurun_out/${TAG}_round.log 2>&1 || { tail -20 gpurun_out/${TAG}_round.log; exit 1; }
+bash tools/gpu_profile_round.sh $TAG c3 ntt c4 c2 > gpurun_out/${TAG}_round.log 2>&1 || { tail -20 gpurun_out/${TAG}_round.log; exit 1; }
 echo "profile passes done"
 timeout -k 10 400 python -u bench.py > gpurun_out/$TAG/bench_c3.json 2> gpurun_out/$TAG/bench_c3.err || { tail -5 gpurun_out/$TAG/bench_c3.err; exit 1; }
 echo "default line done"

@@ -28,10 +28,12 @@ for wl in $WLS; do
         python3 $M/make_valu_json.py $OUT/valu_c3 c3 "c3, default batch per launch, N=2^16 Li=30" $OUT/valu_c3.json relin_rows8p ;;
     ntt) python3 $M/make_traffic_json.py $OUT/pmc_summary_ntt.txt ntt "ntt, 2048 limbs/launch, N=2^16" $OUT/traffic_ntt.json "ntt_cols_kernel<true, false" "ntt_rows8_fwd_kernel<true, 0"
         python3 $M/make_valu_json.py $OUT/valu_ntt ntt "ntt, 2048 limbs/launch, N=2^16" $OUT/valu_ntt.json "ntt_cols_kernel<true, false" "ntt_rows8_fwd_kernel<true, 0" ;;
+    c2) python3 $M/make_traffic_json.py $OUT/pmc_summary_c2.txt c2 "c2, 8192 limbs/launch, N=2^14 (one-pass forward kernel)" $OUT/traffic_c2.json "ntt_onepass_fwd_kernel<true"
+        python3 $M/make_valu_json.py $OUT/valu_c2 c2 "c2, 8192 limbs/launch, N=2^14 (one-pass forward kernel)" $OUT/valu_c2.json "ntt_onepass_fwd_kernel<true" ;;
     c4) python3 $M/make_traffic_json.py $OUT/pmc_summary_c4.txt c4 "c4, default batch per launch, N=2^16 Li=K=30 (mod-down launch: both halves)" $OUT/traffic_c4.json bconv_kernel
         python3 $M/make_valu_json.py $OUT/valu_c4 c4 "c4, default batch per launch, N=2^16 Li=K=30 (mod-down launch: both halves)" $OUT/valu_c4.json bconv_kernel ;;
   esac
 done
 # raw counter dumps are large: keep the summaries and the JSONs
-rm -rf $OUT/fetch_* $OUT/write_* $OUT/valu_c3 $OUT/valu_ntt $OUT/valu_c4 $OUT/stats_*/
+rm -rf $OUT/fetch_* $OUT/write_* $OUT/valu_c3 $OUT/valu_ntt $OUT/valu_c4 $OUT/valu_c2 $OUT/stats_*/
 ls $OUT
