@@ -29,8 +29,8 @@ r = d["ntt"]; cb = r["cpu_baseline"]
 row_replace("| NTT N=2^16", "| NTT N=2^16, 2048 limbs/step (1 GiB, beyond the 256 MB Infinity Cache) | %.2f M limb-NTT/s (≈4 %% more at 512 limbs/step, which the Infinity Cache half absorbs) | %.0f %% | cols+rows pair %s GB/s (%.2f) | %.2f GB (alg 2.15 GB × 2 passes) | %s /s / %s /s | %s |" % (
     r["value"] / 1e6, pct(r), f(r["roofline"]["achieved"]), r["roofline"]["frac"], (r["roofline"]["traffic"] or 0) / 1e9, f(cb["value"]), f(cb["all_cores"]["value"]), ratios(r)))
 r = d["c2"]; cb = r["cpu_baseline"]
-row_replace("| C2 N=2^14", "| C2 N=2^14, 8 limbs × 1024 polys, fwd+inv | %.2f M limb-NTT/s (one-pass kernels; %.2f M with the pass pair) | %.0f %% | `ntt_onepass_fwd_kernel` %s GB/s (%.2f) | — (one pass: algorithmic = actual) | %s /s / %s /s | %s |" % (
-    r["value"] / 1e6, json.load(open("profiles/%s/bench_c2_passpair.json" % RND))["value"] / 1e6, pct(r), f(r["roofline"]["achieved"]), r["roofline"]["frac"], f(cb["value"]), f(cb["all_cores"]["value"]), ratios(r)))
+row_replace("| C2 N=2^14", "| C2 N=2^14, 8 limbs × 1024 polys, fwd+inv | %.2f M limb-NTT/s (one-pass kernels; %.2f M with the pass pair) | %.0f %% | `ntt_onepass_fwd_kernel` %s GB/s (%.2f); VALU issue slots %.0f %% busy | %.2f GB (alg %.2f GB: one pass over HBM) | %s /s / %s /s | %s |" % (
+    r["value"] / 1e6, json.load(open("profiles/%s/bench_c2_passpair.json" % RND))["value"] / 1e6, pct(r), f(r["roofline"]["achieved"]), r["roofline"]["frac"], 100 * r["roofline_valu"]["frac_pmc_pass"], (r["roofline"]["traffic"] or 0) / 1e9, r["roofline"]["alg_bytes_per_launch"] / 1e9, f(cb["value"]), f(cb["all_cores"]["value"]), ratios(r)))
 r = d["c3"]; cb = r["cpu_baseline"]; rf = r["roofline"]
 row_replace("| C3 N=2^16", "| C3 N=2^16, Li=30, batch 16 | %s op/s | %.0f %% | `relin_rows8p_mac_kernel` %s GB/s (%.2f, keys charged once per launch; %.2f with SURVEY's per-op keys); VALU issue slots %.0f %% busy | %.2f GB (alg %.2f GB) | %.2f op/s / %.1f op/s | %s |" % (
     f(r["value"]), pct(r), f(rf["achieved"]), rf["frac"], rf["per_op_keys"]["frac"], 100 * r["roofline_valu"]["frac_pmc_pass"], (rf["traffic"] or 0) / 1e9, rf["alg_bytes_per_launch"] / 1e9, cb["value"], cb["all_cores"]["value"], ratios(r)))
