@@ -968,6 +968,11 @@ __global__ __launch_bounds__(OneCfg<LOGR>::T) void ntt_onepass_inv_kernel(NttArg
         const u32 row = (tid_ >> 5) + it * (T / 32);
         u64 *L = lds + row * ROW8_LDS;
         const u32 baseA = (1u << LOGR) + row;
+        u64 wA[7], wB[7], wC0[3], wC1[3];  // all twiddles of the row requested up front, in the order they are used
+        load_tw<2>(wC0, tw, (baseA << 6) + 2 * t);
+        load_tw<2>(wC1, tw, (baseA << 6) + 2 * t + 1);
+        load_tw<3>(wB, tw, (baseA << 3) + cq);
+        load_tw<3>(wA, tw, baseA);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const ulonglong2 v = pre[4 * it + i];
@@ -983,8 +988,8 @@ __global__ __launch_bounds__(OneCfg<LOGR>::T) void ntt_onepass_inv_kernel(NttArg
         }
         {
           u64 g0[4] = {e[0], e[1], e[2], e[3]}, g1[4] = {e[4], e[5], e[6], e[7]};
-          inv_phase<SP, 2>(g0, tw, (baseA << 6) + 2 * t, P);
-          inv_phase<SP, 2>(g1, tw, (baseA << 6) + 2 * t + 1, P);
+          inv_phase_w<SP, 2>(g0, wC0, P);
+          inv_phase_w<SP, 2>(g1, wC1, P);
 #pragma unroll
           for (int k = 0; k < 4; ++k) { e[k] = g0[k]; e[4 + k] = g1[k]; }
         }
@@ -994,13 +999,13 @@ __global__ __launch_bounds__(OneCfg<LOGR>::T) void ntt_onepass_inv_kernel(NttArg
         wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < 8; ++k) e[k] = L[cq * 36 + r + 4 * k];
-        inv_phase<SP, 3>(e, tw, (baseA << 3) + cq, P);
+        inv_phase_w<SP, 3>(e, wB, P);
 #pragma unroll
         for (int k = 0; k < 8; ++k) L[cq * 36 + r + 4 * k] = e[k];
         wave_lds_sync();
 #pragma unroll
         for (int k = 0; k < 8; ++k) e[k] = L[k * 36 + t];
-        inv_phase<SP, 3>(e, tw, baseA, P);
+        inv_phase_w<SP, 3>(e, wA, P);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { DBG_RANGE(e[k], P.twop, 5); L[k * 36 + t] = e[k]; }
       }
