@@ -58,31 +58,33 @@ GENERIC = ("rotm", "rotnn", "dec", "enc")
 MULT = ("c3", "c5")
 
 
+def _is_prime_host(n):
+    if n < 2:
+        return False
+    small = (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37)
+    for q in small:
+        if n % q == 0:
+            return n == q
+    d, r = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        r += 1
+    for a in small:
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(r - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
 def gen_primes_host(logN, count):
     """The repo's prime table (same rule as oracle/fhe_oracle.c:orc_gen_primes) without touching the oracle."""
-    def is_prime(n):
-        if n < 2:
-            return False
-        small = (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37)
-        for q in small:
-            if n % q == 0:
-                return n == q
-        d, r = n - 1, 0
-        while d % 2 == 0:
-            d //= 2
-            r += 1
-        for a in small:
-            x = pow(a, d, n)
-            if x in (1, n - 1):
-                continue
-            for _ in range(r - 1):
-                x = x * x % n
-                if x == n - 1:
-                    break
-            else:
-                return False
-        return True
-
+    is_prime = _is_prime_host
     pr, ps = [], []
     k = (1 << 30) - 1
     while len(pr) < count:
@@ -95,6 +97,24 @@ def gen_primes_host(logN, count):
             x += 1
         pr.append(p)
         ps.append(pow(x, (p - 1) >> (logN + 1), p))
+    return np.array(pr, np.uint64), np.array(ps, np.uint64)
+
+
+def gen_generic_primes_host(logN, count):
+    """`--primes generic`: descending 62-bit primes with 2N | p - 1 that are NOT of the k*2^32 + 1 form, i.e. a table like the
+    one a drop-in caller passes (yell's params::P); the library then runs its generic-prime kernel instantiations."""
+    base = _is_prime_host
+    pr, ps = [], []
+    step = 1 << (logN + 1)
+    p = (1 << 62) - step + 1
+    while len(pr) < count:
+        if p % (1 << 32) != 1 and base(p):
+            x = 2
+            while pow(x, (p - 1) // 2, p) != p - 1:
+                x += 1
+            pr.append(p)
+            ps.append(pow(x, (p - 1) >> (logN + 1), p))
+        p -= step
     return np.array(pr, np.uint64), np.array(ps, np.uint64)
 
 
@@ -254,7 +274,7 @@ def read_profile_json(kind, workload):
 class Setup:
     """One workload on one context: synthetic HBM-resident inputs and the step() that runs the hot path over them."""
 
-    def __init__(self, workload, B, local_rank, rank, sb=None, relin_group=0, ntt_chunk=0, onepass=1):
+    def __init__(self, workload, B, local_rank, rank, sb=None, relin_group=0, ntt_chunk=0, onepass=1, primes="sp", ntt_streams=2):
         import torch
         import fhe_amd
         self.workload = workload
@@ -262,7 +282,8 @@ class Setup:
         self.B = B or dflt
         logN, L, K, Li, B = self.logN, self.L, self.K, self.Li, self.B
         self.N = N = 1 << logN
-        self.primes, self.psi = gen_primes_host(logN, L + K)
+        self.primes_kind = primes
+        self.primes, self.psi = (gen_generic_primes_host if primes == "generic" else gen_primes_host)(logN, L + K)
         self.ctx = ctx = fhe_amd.HipContext(logN, L, K, self.primes, self.psi, device=local_rank)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         if relin_group:
@@ -271,6 +292,8 @@ class Setup:
             ctx.set_tuning(fhe_amd.hip.TUNE_NTT_CHUNK, ntt_chunk)
         if not onepass:
             ctx.set_tuning(fhe_amd.hip.TUNE_ONEPASS, 0)
+        if ntt_streams != 2:
+            ctx.set_tuning(fhe_amd.hip.TUNE_NTT_STREAMS, ntt_streams)
         gen = torch.Generator(device="cuda").manual_seed(0x5EED0000 + rank)
 
         def rnd(*shape):  # uniform residues below 2^61 (< every prime of the table)
@@ -397,6 +420,12 @@ class Setup:
             launches, ms = kms("bconv_moddown")   # the larger of the two conversion launches: both halves' mod-down in one
             kname = "bconv_kernel (mod-down of both halves, one launch)"
             units_per_launch = B
+        elif kms("ntt_fwd_overlapped")[0]:
+            # N >= 2^15: the library issues the call's chunks on two internal streams (column pass of one chunk under the row pass of
+            # another), so per-kernel durations overlap; the unit timed is the whole call, first launch -> last completion
+            launches, ms = kms("ntt_fwd_overlapped")
+            kname = "ntt_fwd: ntt_cols_kernel + ntt_rows8_fwd_kernel over the whole call (128-limb chunks overlapped on two streams; first launch -> last completion)"
+            units_per_launch = B
         elif kms("ntt_fwd_onepass")[0]:  # N <= 2^14: the limb stays in one workgroup's LDS, one kernel per transform
             launches, ms = kms("ntt_fwd_onepass")
             kname = "ntt_onepass_fwd_kernel"
@@ -414,7 +443,7 @@ class Setup:
         else:
             alg, per_op = dominant_kernel_bytes(w, N, Li, K, units_per_launch)
         achieved = alg / (avg_ms * 1e-3) / 1e9
-        default_batch = self.B == WORKLOADS[w][4]
+        default_batch = self.B == WORKLOADS[w][4] and self.primes_kind == "sp"  # the committed counter passes ran this shape on the SP table
         tj = read_profile_json("traffic", w) if default_batch else None
         traffic = tj.get("hbm_bytes_per_launch") if tj else None
         roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -459,7 +488,11 @@ def main():
     ap.add_argument("--no-ntt-n16", action="store_true", help="skip the ntt_n16 sub-record of the default (c3) run")
     ap.add_argument("--relin-group", type=int, default=0, help="FHE_HIP_TUNE_RELIN_GROUP (0 = library default)")
     ap.add_argument("--ntt-chunk", type=int, default=0, help="FHE_HIP_TUNE_NTT_CHUNK (0 = library default)")
+    ap.add_argument("--ntt-streams", type=int, default=2, help="FHE_HIP_TUNE_NTT_STREAMS: 1 = stand-alone NTTs at N >= 2^15 on one stream (A/B)")
     ap.add_argument("--onepass", type=int, default=1, help="FHE_HIP_TUNE_ONEPASS: 0 = column/row pass pair also for N <= 2^14")
+    ap.add_argument("--primes", default="sp", choices=("sp", "generic"),
+                    help="sp: the repo's k*2^32+1 table (multiplication-free Montgomery quotient); generic: 62-bit primes of no special "
+                         "form, the kernels a caller's own table (yell's params::P) runs")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="run the ranks of --gpus N on the GPUs that exist (rank %% device count) over gloo: exercises the multi-rank "
                          "logic (barriers, key broadcast, parity check, --e2e) on a one-GPU box; the line is marked and is not a measurement")
@@ -511,7 +544,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    su = Setup(args.workload, args.batch, local_rank, rank, sb, args.relin_group, args.ntt_chunk, args.onepass)
+    su = Setup(args.workload, args.batch, local_rank, rank, sb, args.relin_group, args.ntt_chunk, args.onepass, args.primes, args.ntt_streams)
     logN, L, K, Li, N, B = su.logN, su.L, su.K, su.Li, su.N, su.B
     elapsed, prof = su.timed(args.steps, args.warmup, args.prewarm, barrier)
     elapsed = max_over_ranks(elapsed)
@@ -524,6 +557,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": "%s: N=2^%d Li=%d K=%d, %d units/step/GPU" % (args.workload, logN, Li, K, su.per_step_units),
+                   "primes": "k*2^32+1 table (SP kernels)" if args.primes == "sp" else "generic 62-bit primes (generic-prime kernels)",
                    "parallelism": "independent ciphertexts sharded over %d GPU(s), no data-path collective" % world},
         "roofline_whole_op": {"alg_bytes_per_unit": alg, "achieved_GBs": value / world * alg / 1e9,
                               "frac_of_hbm_peak": value / world * alg / 1e9 / HBM_PEAK_GBS},
@@ -600,7 +634,7 @@ def main():
     # ---- the other headline figure on the same line: batched forward limb-NTT at N = 2^16 ---------------------------------
     if args.workload == "c3" and not args.no_ntt_n16 and not args.batch:
         del su.c0, su.c1, su.out
-        nt = Setup("ntt", 0, local_rank, rank)
+        nt = Setup("ntt", 0, local_rank, rank, primes=args.primes, ntt_streams=args.ntt_streams, ntt_chunk=args.ntt_chunk)
         el, npf = nt.timed(2 * args.steps, args.warmup, args.prewarm, barrier)
         el = max_over_ranks(el)
         nroof, nvalu = nt.roofline(npf, 2 * args.steps)

@@ -88,6 +88,12 @@ struct fhe_hip_ctx {
   int num_cus = 256;         // persistent kernels size their grids by it
   uint32_t onepass = 1;      // N = 2^12 .. 2^14: plain NTTs as one kernel with the limb in LDS (FHE_HIP_TUNE_ONEPASS)
   uint32_t ntt_chunk = 0;    // limbs per pass pair of fhe_hip_ntt_forward / _backward (0 = as many as one grid takes)
+  // fhe_hip_ntt_forward / _backward at N >= 2^15 (two passes over memory): chunks of the call are issued alternately on two
+  // library-owned streams, forked from and joined to the caller's stream by events, so that one chunk's column pass runs under
+  // another chunk's row pass and a chunk's intermediate is re-read from the Infinity Cache (FHE_HIP_TUNE_NTT_STREAMS)
+  uint32_t ntt_streams = 2;
+  hipStream_t ntt_aux[2] = {nullptr, nullptr};
+  hipEvent_t ntt_fork = nullptr, ntt_join[2] = {nullptr, nullptr};
   void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t stage_bytes[4] = {0, 0, 0, 0};
   // per-launch timing: consecutive launches share an event (end of one = start of the next) while nothing else was enqueued
@@ -276,8 +282,10 @@ int launch_rows(fhe_hip_ctx *c, const NttArgs &a, u32 nl, u32 batch) {
     if (a.epi == 4) { LAUNCH(c, "ntt_fwd_rows_rotdown", (ntt_rows8_fwd_kernel<SP, 4>), grid, block, a); return FHE_HIP_OK; }
     LAUNCH(c, "ntt_fwd_rows", (ntt_rows8_fwd_kernel<SP, 0>), grid, block, a);
   } else {
-    if (a.pre_a) LAUNCH(c, "ntt_inv_rows_decrypt", (ntt_rows8_inv_kernel<SP, true>), grid, block, a);
-    else LAUNCH(c, "ntt_inv_rows", (ntt_rows8_inv_kernel<SP, false>), grid, block, a);
+    if (a.pre_a && a.perm) FAIL(c, FHE_HIP_ERR_ARG, "internal: inverse row pass with both a gather and a pre-multiply");
+    if (a.pre_a) LAUNCH(c, "ntt_inv_rows_decrypt", (ntt_rows8_inv_kernel<SP, true, false>), grid, block, a);
+    else if (a.perm) LAUNCH(c, "ntt_inv_rows", (ntt_rows8_inv_kernel<SP, false, true>), grid, block, a);
+    else LAUNCH(c, "ntt_inv_rows", (ntt_rows8_inv_kernel<SP, false, false>), grid, block, a);
   }
   return FHE_HIP_OK;
 }
@@ -340,6 +348,9 @@ int ntt_run_sp(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
 int ntt_run(fhe_hip_ctx *c, const NttPlan &p, bool inverse) {
   // grid.y / grid.z limits: split large limb counts over several launches
   if (p.skip_diag && p.skip_diag != p.mdiv) FAIL(c, FHE_HIP_ERR_ARG, "internal: skip_diag must equal mdiv");
+  // a limb offset is only meaningful for a forward column-pass-only plan: the in-place second pass addresses its source by
+  // (limb id) mod nl, and an inverse plan's first pass would do the same with the row pass
+  if (p.l0 != 0 && (!p.cols_only || inverse)) FAIL(c, FHE_HIP_ERR_ARG, "internal: NttPlan::l0 needs a forward cols_only plan");
   if (p.nl + p.l0 > 65535 || p.batch > 65535 || p.mdiv > 65535 || p.mper > 65535 || p.smod > 65535)
     FAIL(c, FHE_HIP_ERR_RANGE, "too many limbs in one NTT launch");  // also the range limb_div is exact on
   return c->sp ? ntt_run_sp<true>(c, p, inverse) : ntt_run_sp<false>(c, p, inverse);
@@ -480,7 +491,9 @@ int dev_relin(fhe_hip_ctx *c, u64 *out, const u64 *ct3, u32 Li, u32 batch) {
   u32 chunk = batch;
   if (c->fixed_ws) {
     // everything has to fit what is left of the fixed scratch buffer: whole batch at once, the largest group that fits
-    const size_t left = (size_t)FHE_HIP_NOALLOC_SCRATCH_BYTES - c->fixed_used, limb = (size_t)N * 8 + 256;
+    // (limbs are multiples of 256 bytes for every supported N, so ensure_ws rounds nothing up: the same count as the entry point's
+    // precheck batch * (9 Li - 2) limbs, which therefore guarantees g >= 1 here)
+    const size_t left = (size_t)FHE_HIP_NOALLOC_SCRATCH_BYTES - c->fixed_used, limb = (size_t)N * 8;
     const size_t pw_limbs = (size_t)batch * Li;
     if (left / limb <= pw_limbs) FAIL(c, FHE_HIP_ERR_RANGE, "operands too large for the fixed scratch buffer (FHE_HIP_NOALLOC_SCRATCH_BYTES)");
     const size_t g = (left / limb - pw_limbs) / ((size_t)batch * Li);
@@ -728,6 +741,9 @@ int fhe_hip_ctx_create(fhe_hip_ctx **out, uint32_t logN, uint32_t L, uint32_t K,
     if (h_powmod(psi[m], N, p) != p - 1) { c->err = "psi is not a primitive 2N-th root of unity"; return fail(FHE_HIP_ERR_RANGE); }
     if ((p & 0xFFFFFFFFull) != 1) c->sp = false;
   }
+  // measured (profiles/r03/ntt_streams.txt): the two-stream form gains 4 % on the SP kernels, which sit nearer the memory
+  // system's limit, and nothing on the generic-prime kernels (30 % more instructions per butterfly for the same bytes)
+  c->ntt_streams = c->sp ? 2 : 1;
   {
     // the lazy butterflies take residues of one prime of the table as inputs under another (relinearisation digits, rescale
     // tails, mixed rotation) and need them below 4p: primes of one table must lie within a factor 4 of each other; equal
@@ -753,10 +769,10 @@ int fhe_hip_ctx_create(fhe_hip_ctx **out, uint32_t logN, uint32_t L, uint32_t K,
   for (uint32_t m = 0; m < M; ++m) {
     const u64 p = primes[m];
     PrimeC &P = pc[m];
-    P.p = p; P.twop = 2 * p; P.p1 = (u32)(p >> 32); P.pad = 0;
+    P.p = p; P.twop = 2 * p; P.p1 = (u32)(p >> 32);
     u64 inv = 1;  // Newton iteration for p^-1 mod 2^64
     for (int i = 0; i < 6; ++i) inv *= 2 - p * inv;
-    P.pinv = inv;
+    P.pinv = inv; P.n32 = 0u - (u32)inv;
     P.r2 = (u64)((((u128)h_to_mont(1, p)) << 64) % p);
     P.ninv_m = h_to_mont(h_invmod(N % p, p), p);
     const u64 ps = psi[m] % p, psinv = h_invmod(ps, p);
@@ -824,6 +840,8 @@ void fhe_hip_ctx_destroy(fhe_hip_ctx *c) {
   for (void *p : c->ws) if (p) hipFree(p);
   for (void *p : c->stage) if (p) hipFree(p);
   if (c->d_idx) hipFree(c->d_idx);
+  for (int k = 0; k < 2; ++k) { if (c->ntt_aux[k]) hipStreamDestroy(c->ntt_aux[k]); if (c->ntt_join[k]) hipEventDestroy(c->ntt_join[k]); }
+  if (c->ntt_fork) hipEventDestroy(c->ntt_fork);
   for (int k = 0; k < 3; ++k) {
     for (int j = 0; j < 3; ++j) if (c->br_buf[k][j]) hipFree(c->br_buf[k][j]);
     for (int l = 0; l < 2; ++l) if (c->br_ev_up[l][k]) hipEventDestroy(c->br_ev_up[l][k]);
@@ -839,6 +857,7 @@ void fhe_hip_ctx_destroy(fhe_hip_ctx *c) {
 int fhe_hip_set_stream(fhe_hip_ctx *c, void *s) { TRY(check_ctx(c)); c->stream = (hipStream_t)s; return FHE_HIP_OK; }
 int fhe_hip_sync(fhe_hip_ctx *c) { TRY(check_ctx(c)); HIPCHK(c, hipStreamSynchronize(c->stream)); return FHE_HIP_OK; }
 
+constexpr size_t NTT_OVERLAP_CHUNK = 128;  // limbs per chunk of the two-stream form: a 64 MB intermediate at N = 2^16 (profiles/r02/ntt_streams.txt)
 static int ntt_api(fhe_hip_ctx *c, uint64_t *limbs, const uint32_t *moduli_idx, size_t n_limbs, int mem_kind, bool inverse) {
   try {
   TRY(check_ctx(c));
@@ -859,6 +878,50 @@ static int ntt_api(fhe_hip_ctx *c, uint64_t *limbs, const uint32_t *moduli_idx, 
     HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(c->d_idx, c->h_idx.data(), n_limbs * sizeof(u32), hipMemcpyHostToDevice, c->stream)));
   }
   u32 *dm = c->d_idx;
+  // Two passes over memory (N >= 2^15) and enough limbs: overlapped chunks on the two library-owned streams.  Kernel boundaries
+  // order each chunk's passes (same stream) and make its intermediate visible; chunks touch disjoint limbs.
+  const size_t ochunk = c->ntt_chunk ? c->ntt_chunk : NTT_OVERLAP_CHUNK;
+  if (c->ntt_streams >= 2 && c->logR >= 7 && n_limbs >= 2 * ochunk) {
+    if (!c->ntt_aux[0]) {
+      for (int k = 0; k < 2; ++k) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->ntt_aux[k], hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ntt_join[k], hipEventDisableTiming));
+      }
+      HIPCHK(c, hipEventCreateWithFlags(&c->ntt_fork, hipEventDisableTiming));
+    }
+    // per-launch timing would time kernels that overlap each other: the whole call is one profile entry instead
+    // (first launch -> last completion, measured on the caller's stream around the fork and the join)
+    const bool prof = c->prof;
+    hipEvent_t ev0 = nullptr;
+    if (prof) { ev0 = prof_event(c); c->prof = false; }
+    hipStream_t user = c->stream;
+    int rc = FHE_HIP_OK;
+    hipError_t e = hipEventRecord(c->ntt_fork, user);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipStreamWaitEvent(c->ntt_aux[k], c->ntt_fork, 0);
+    size_t i = 0;
+    for (size_t off = 0; off < n_limbs && e == hipSuccess && rc == FHE_HIP_OK; off += ochunk, ++i) {
+      const u32 n = (u32)((n_limbs - off < ochunk) ? n_limbs - off : ochunk);
+      NttPlan p{d + off * c->N, d + off * c->N, dm + off, 1, n, n, n, 1, 0, 0};
+      c->stream = c->ntt_aux[i & 1];
+      rc = ntt_run(c, p, inverse);
+      c->stream = user;
+    }
+    // join on every path, so that the caller's stream never runs ahead of work already enqueued on the side streams
+    for (int k = 0; k < 2; ++k) {
+      hipError_t e2 = hipEventRecord(c->ntt_join[k], c->ntt_aux[k]);
+      if (e2 == hipSuccess) e2 = hipStreamWaitEvent(user, c->ntt_join[k], 0);
+      if (e == hipSuccess) e = e2;
+    }
+    c->prof = prof;
+    if (e != hipSuccess) { c->err = std::string("two-stream NTT: ") + hipGetErrorString(e); return FHE_HIP_ERR_HIP; }
+    TRY(rc);
+    if (prof) {
+      hipEvent_t ev1 = prof_event(c);
+      prof_entry(c, inverse ? "ntt_inv_overlapped" : "ntt_fwd_overlapped")->pending.push_back({ev0, ev1});
+      c->chain_valid = false;
+    }
+    return st.finish();
+  }
   const size_t step = c->ntt_chunk ? c->ntt_chunk : 32768;
   for (size_t off = 0; off < n_limbs; off += step) {
     const u32 n = (u32)((n_limbs - off < step) ? n_limbs - off : step);
@@ -1113,7 +1176,24 @@ int fhe_hip_mul_relin_rescale(fhe_hip_ctx *c, uint64_t *out, const uint64_t *c0,
 
 // fhe_hip_mul_relin_rescale for callers that cannot allocate: same kernels, every workspace carved out of this device's copy
 // of fhe_hip_scratch (address taken in fhe_hip_ctx_create).  Calls no hipMalloc / hipFree / event creation; device pointers only.
+namespace {
+// sets the context's grow-only workspaces aside and routes ensure_ws to the static scratch array; puts everything back on
+// every exit path (return, error, exception)
+struct FixedWsScope {
+  fhe_hip_ctx *c; void *saved_ws[6]; size_t saved_bytes[6];
+  explicit FixedWsScope(fhe_hip_ctx *ctx) : c(ctx) {
+    for (int k = 0; k < 6; ++k) { saved_ws[k] = c->ws[k]; saved_bytes[k] = c->ws_bytes[k]; c->ws[k] = nullptr; c->ws_bytes[k] = 0; }
+    c->fixed_ws = true; c->fixed_used = 0;
+  }
+  ~FixedWsScope() {
+    c->fixed_ws = false; c->fixed_used = 0;
+    for (int k = 0; k < 6; ++k) { c->ws[k] = saved_ws[k]; c->ws_bytes[k] = saved_bytes[k]; }
+  }
+};
+}  // namespace
+
 int fhe_hip_mul_relin_rescale_noalloc(fhe_hip_ctx *c, uint64_t *out, const uint64_t *c0, const uint64_t *c1, uint32_t Li, size_t batch) {
+  try {
   if (!c) return FHE_HIP_ERR_ARG;
   TRY(check_ctx(c));
   if (!out || !c0 || !c1) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
@@ -1126,13 +1206,9 @@ int fhe_hip_mul_relin_rescale_noalloc(fhe_hip_ctx *c, uint64_t *out, const uint6
   if (batch > (size_t)FHE_HIP_NOALLOC_SCRATCH_BYTES / ((size_t)(9 * Li - 2) * limb))
     FAIL(c, FHE_HIP_ERR_RANGE, "batch * (9 Li - 2) * N * 8 bytes exceeds FHE_HIP_NOALLOC_SCRATCH_BYTES: split the batch");
   // the grow-only workspaces of the allocating entry points are set aside for the duration of this call
-  void *saved_ws[6]; size_t saved_bytes[6];
-  for (int k = 0; k < 6; ++k) { saved_ws[k] = c->ws[k]; saved_bytes[k] = c->ws_bytes[k]; c->ws[k] = nullptr; c->ws_bytes[k] = 0; }
-  c->fixed_ws = true; c->fixed_used = 0;
-  const int rc = dev_mul_relin_rescale(c, (u64 *)out, (const u64 *)c0, (const u64 *)c1, Li, (u32)batch);
-  c->fixed_ws = false;
-  for (int k = 0; k < 6; ++k) { c->ws[k] = saved_ws[k]; c->ws_bytes[k] = saved_bytes[k]; }
-  return rc;
+  FixedWsScope scope(c);
+  return dev_mul_relin_rescale(c, (u64 *)out, (const u64 *)c0, (const u64 *)c1, Li, (u32)batch);
+  } catch (...) { return abi_exception(); }
 }
 
 int fhe_hip_set_tuning(fhe_hip_ctx *c, int knob, uint64_t value) {
@@ -1140,6 +1216,7 @@ int fhe_hip_set_tuning(fhe_hip_ctx *c, int knob, uint64_t value) {
   if (knob == FHE_HIP_TUNE_RELIN_GROUP) { c->relin_group = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return FHE_HIP_OK; }
   if (knob == FHE_HIP_TUNE_ONEPASS) { c->onepass = value ? 1u : 0u; return FHE_HIP_OK; }
   if (knob == FHE_HIP_TUNE_NTT_CHUNK) { c->ntt_chunk = value > 32768 ? 32768u : (uint32_t)value; return FHE_HIP_OK; }
+  if (knob == FHE_HIP_TUNE_NTT_STREAMS) { c->ntt_streams = value >= 2 ? 2u : 1u; return FHE_HIP_OK; }
   FAIL(c, FHE_HIP_ERR_ARG, "unknown tuning knob");
 }
 
@@ -1154,8 +1231,14 @@ int fhe_hip_rotate_to(fhe_hip_ctx *c, uint64_t galois, uint64_t *out, const uint
   try {
   TRY(check_ctx(c));
   if (!out || !in) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
-  if (out == in) FAIL(c, FHE_HIP_ERR_ARG, "fhe_hip_rotate_to is out of place: out must differ from in (fhe_hip_rotate works in place)");
+  TRY(check_li(c, Li, 1));
   const size_t bytes = batch * 2 * Li * c->N * 8;
+  {
+    // out of place means disjoint: the last kernel still gathers `in` through the galois table while it writes `out`
+    const uintptr_t a = (uintptr_t)in, b = (uintptr_t)out;
+    if (a == b || (bytes && a < b + bytes && b < a + bytes))
+      FAIL(c, FHE_HIP_ERR_ARG, "fhe_hip_rotate_to is out of place: out must not overlap in (fhe_hip_rotate works in place)");
+  }
   if (galois == 0) {  // no rotation (evaluator.cpp:303-304): the result is the input
     if (batch == 0) return FHE_HIP_OK;
     if (mem_kind == FHE_HIP_MEM_DEVICE) HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, c->stream)));

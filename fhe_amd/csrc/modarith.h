@@ -21,7 +21,7 @@ struct PrimeC {
   u64 r2;      // 2^128 mod p  (to-Montgomery factor)
   u64 ninv_m;  // N^-1 mod p in Montgomery form
   u32 p1;      // p >> 32
-  u32 pad;
+  u32 n32;     // -p^-1 mod 2^32 (quotient digit factor of the generic word-serial Montgomery steps)
 };
 
 __device__ __forceinline__ u64 mad_wide(u32 a, u32 b, u64 c) { return (u64)a * (u64)b + c; }
@@ -72,6 +72,8 @@ __device__ __forceinline__ u64 csub(u64 x, u64 m) { return x >= m ? x - m : x; }
 // 64-bit add of -m, kept opaque so that it is not turned back into a two-instruction borrow chain
 __device__ __forceinline__ u64 csub_u(u64 x, u64 m) {
   u64 negm = 0 - m;
+  // (readfirstlane: the modulus is wave-uniform, but where its words also feed vector operands the compiler may keep it in VGPRs)
+  negm = ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(negm >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((u32)negm);  // (the builtin returns int)
   asm("" : "+s"(negm));
   return x >= m ? x + negm : x;
 }
@@ -106,6 +108,12 @@ __device__ __forceinline__ u64 mad_op0(u32 a, u32 b) {
 __device__ __forceinline__ u64 mad_op(u32 a, u32 b, u64 c) {
   u64 d, cc;
   asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cc) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+// a*b + k with the 64-bit addend in a scalar pair (wave-uniform constant)
+__device__ __forceinline__ u64 mad_op_s(u32 a, u32 b, u64 k) {
+  u64 d, cc;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cc) : "v"(a), "v"(b), "s"(k));
   return d;
 }
 __device__ __forceinline__ u64 pair64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
@@ -159,24 +167,68 @@ __device__ __forceinline__ u64 mad_op_carry(u32 a, u32 b, u64 c, u32 &carry) {
 //   step 2 (subtractive): V - V0*p has a zero low word:  D = a1*b1 + (V2:V1) - V0*p1.
 // c0 comes for free as the carry of adding 2^32 - 1 inside the first multiply-add.
 // 6 multiply-adds + 2 carry-word operations + 4 plain ones (the product-then-reduce form compiles to 6 + 18).
-template <bool SP>
-__device__ __forceinline__ u64 mont_diff(u64 a, u64 b, const PrimeC &P) {
-  if constexpr (SP) {
-    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    const u32 p1 = P.p1;
-    const u64 t0 = mad_op_k(a0, b0);                      // a0*b0 + 2^32 - 1 <= 2^64 - 2^32: (T0 - 1, h0 + c0)
-    const u64 t1 = mad_op(a1, b0, t0 >> 32);              // < 2^62 + 2^32 (a move and a shared zero: cheaper than a 64-bit shift)
-    const u64 m = mad_op(~(u32)t0, p1, t1);               // q0 = -T0 = ~(T0 - 1);  < 2^63 + 2^32
-    u32 V2, w1, w2;
-    const u64 t2 = mad_op_carry(a0, b1, m, V2);
-    const u32 V0 = (u32)t2, V1 = (u32)(t2 >> 32);
-    const u64 n = mad_op0(V0, p1);
+//
+// Generic primes (any odd p < 2^62; the table a drop-in caller passes, e.g. yell's params::P): the same word-serial scheme
+// with the quotient digits q = T0 * (-+p^-1 mod 2^32) (one v_mul_lo_u32 each) and the products q*p0 (p0 = p mod 2^32):
+//   step 1 (additive):  q0 = T0 * n32:  (a0*b0 + q0*p0) / 2^32 = hi(u) + 2^32 cu with u = q0*p0 + a0*b0 (low word zero,
+//        65 bits: carry cu), which is the addend of a1*b0;  V = that + q0*p1 + a0*b1                       (65 bits: V2:V1:V0)
+//   step 2 (subtractive, signed result): q1 = V0 * pinv32;  D = a1*b1 + (V2:V1) - q1*p1 - hi(q1*p0)         in (-p, p)
+//        (additive, mont_mul): q1 = V0 * n32;  M = a1*b1 + (V2:V1) + q1*p1 + hi(q1*p0 + 2^32 - 1)            in [0, 2p)
+// 8 multiply-adds + 2 low multiplies + 6 word operations = 16 (the product-then-reduce form it replaces compiled to 11 + ~20).
+template <bool ADDITIVE>
+__device__ __forceinline__ u64 mont_generic(u64 a, u64 b, const PrimeC &P) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  const u32 p0 = (u32)P.p, p1 = P.p1, pinv32 = (u32)P.pinv, n32 = P.n32;  // (n32 from the table: computed here, the compiler negates every quotient instead)
+  const u64 t0 = mad_op0(a0, b0);
+  const u32 q0 = (u32)t0 * n32;
+  u32 cu, V2;
+  const u64 u = mad_op_carry(q0, p0, t0, cu);             // low word 0
+  const u64 t1 = mad_op(a1, b0, pair64((u32)(u >> 32), cu));  // < 2^62 + 2^33
+  const u64 m = mad_op(q0, p1, t1);                       // < 2^63 + 2^33
+  const u64 t2 = mad_op_carry(a0, b1, m, V2);
+  const u32 V0 = (u32)t2, V1 = (u32)(t2 >> 32);
+  if constexpr (ADDITIVE) {
+    const u32 q1 = V0 * n32;
+    const u64 w = mad_op_k(q1, p0);                       // high word = hi(q1*p0) + (V0 != 0)
+    const u64 n = mad_op(q1, p1, w >> 32);
+    u32 w1, w2;
+    const u32 elo = __builtin_addc(V1, (u32)n, 0u, &w1);
+    const u32 ehi = __builtin_addc(V2, (u32)(n >> 32), w1, &w2);
+    return mad_op(a1, b1, pair64(elo, ehi));
+  } else {
+    const u32 q1 = V0 * pinv32;
+    const u64 w = mad_op0(q1, p0);                        // low word = V0
+    const u64 n = mad_op(q1, p1, w >> 32);
+    u32 w1, w2;
     const u32 elo = __builtin_subc(V1, (u32)n, 0u, &w1);
     const u32 ehi = __builtin_subc(V2, (u32)(n >> 32), w1, &w2);
     return mad_op(a1, b1, pair64(elo, ehi));
-  } else {
-    return mont_diff_ref<false>(a, b, P);
   }
+}
+
+// SP core with a constant offset: returns D + off (mod 2^64), off wave-uniform.  The offset rides in the addend of the step-2
+// multiply-add (n - off instead of n; everything downstream is arithmetic mod 2^64), so "+ p" costs no instruction.
+template <bool OFF>
+__device__ __forceinline__ u64 mont_sp(u64 a, u64 b, const PrimeC &P, u64 negoff) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  const u32 p1 = P.p1;
+  const u64 t0 = mad_op_k(a0, b0);                      // a0*b0 + 2^32 - 1 <= 2^64 - 2^32: (T0 - 1, h0 + c0)
+  const u64 t1 = mad_op(a1, b0, t0 >> 32);              // < 2^62 + 2^32 (a move and a shared zero: cheaper than a 64-bit shift)
+  const u64 m = mad_op(~(u32)t0, p1, t1);               // q0 = -T0 = ~(T0 - 1);  < 2^63 + 2^32
+  u32 V2, w1, w2;
+  const u64 t2 = mad_op_carry(a0, b1, m, V2);
+  const u32 V0 = (u32)t2, V1 = (u32)(t2 >> 32);
+  u64 n;
+  if constexpr (OFF) n = mad_op_s(V0, p1, negoff); else n = mad_op0(V0, p1);
+  const u32 elo = __builtin_subc(V1, (u32)n, 0u, &w1);
+  const u32 ehi = __builtin_subc(V2, (u32)(n >> 32), w1, &w2);
+  return mad_op(a1, b1, pair64(elo, ehi));
+}
+
+template <bool SP>
+__device__ __forceinline__ u64 mont_diff(u64 a, u64 b, const PrimeC &P) {
+  if constexpr (SP) return mont_sp<false>(a, b, P, 0);
+  else return mont_generic<false>(a, b, P);
 }
 
 // mont_diff with a wave-uniform first factor (a twiddle that every lane of the workgroup shares, held in scalar registers):
@@ -214,16 +266,12 @@ __device__ __forceinline__ void ct_bfly_ua(u64 &X, u64 &Y, u64 W_uniform, const 
 template <bool SP>
 __device__ __forceinline__ u64 mont_mul(u64 a, u64 b, const PrimeC &P) {
   if constexpr (SP) {
-    return mont_diff<true>(a, b, P) + P.p;
-  } else {
-    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    const u64 t0 = mad_wide(a0, b0, 0);
-    const u64 t1 = mad_wide(a0, b1, t0 >> 32);
-    const u64 t2 = mad_wide(a1, b0, (u64)(u32)t1);
-    const u64 thi = mad_wide(a1, b1, (t1 >> 32) + (t2 >> 32));
-    const u64 tlo = (t2 << 32) | (u64)(u32)t0;
-    return mont_reduce<false>(thi, tlo, P);
+    // D + p with the offset folded (no instruction).  The modulus is wave-uniform in every kernel; the readfirstlane pair only
+    // tells the compiler so where it holds the constant in vector registers (it folds away where P already sits in SGPRs).
+    const u64 negp = 0 - P.p;
+    return mont_sp<true>(a, b, P, pair64(__builtin_amdgcn_readfirstlane((u32)negp), __builtin_amdgcn_readfirstlane((u32)(negp >> 32))));
   }
+  else return mont_generic<true>(a, b, P);
 }
 
 template <bool SP>
@@ -250,5 +298,5 @@ __device__ __forceinline__ void gs_bfly(u64 &X, u64 &Y, u64 W, const PrimeC &P) 
   const u64 s = X + Y;
   const u64 d = X - Y + P.twop;
   X = csub_u(s, P.twop);
-  Y = mont_diff<SP>(W, d, P) + P.p;
+  Y = mont_mul<SP>(W, d, P);
 }

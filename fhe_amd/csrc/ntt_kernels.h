@@ -78,8 +78,7 @@ __device__ __forceinline__ u64 canon4(u64 v, const PrimeC &P) { return csub_u(cs
 template <bool SP>
 __device__ __forceinline__ u64 lazy_acc(u64 acc, u64 k, u64 x, const PrimeC &P) {
   const u64 xp = (acc >= P.twop) ? acc - P.p : acc + P.p;
-  if constexpr (SP) return xp + mont_diff<true>(k, x, P);
-  else return xp + (mont_mul<false>(k, x, P) - P.p);
+  return xp + mont_diff<SP>(k, x, P);
 }
 
 template <bool SP, int LK>
@@ -294,7 +293,9 @@ __global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
 
 // Row pass of the inverse NTT, 8 elements per thread (mirror of ntt_rows8_fwd_kernel): spans 1, 2 | 4, 8, 16 | 32, 64, 128;
 // coalesced 16-byte loads (optionally gathered through a galois index table), output lazy in [0,2p) for the column pass.
-template <bool SP, bool PRE = false>
+// PERM: the source is read through NttArgs::perm (a template parameter, not a run-time test: the four loads of a thread then
+// issue back to back instead of each waiting for the one before it behind a branch).
+template <bool SP, bool PRE = false, bool PERM = false>
 __global__ __launch_bounds__(256) void ntt_rows8_inv_kernel(NttArgs a) {
   __shared__ __attribute__((aligned(16))) u64 lds[8 * ROW8_LDS];
   const u32 tid = threadIdx.x, rloc = tid >> 5, t = tid & 31;
@@ -309,25 +310,38 @@ __global__ __launch_bounds__(256) void ntt_rows8_inv_kernel(NttArgs a) {
   u64 *L = lds + rloc * ROW8_LDS;
   const u32 baseA = (1u << a.logR) + row;
   const u32 c = t >> 2, r = t & 3, p0 = row8_pos(8 * t);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const u32 el = 64 * i + 2 * t;
-    ulonglong2 v;
-    if (a.perm) {
+  {
+    ulonglong2 v[4];
+    if constexpr (PERM) {
       const u64 *sl = s - (u64)row * 256;  // limb base
-      v = gather_pair(sl, a.perm[row * 256 + el]);
+      u32 pd[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pd[i] = a.perm[row * 256 + 64 * i + 2 * t];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = gather_pair(sl, pd[i]);
     } else {
-      v = *reinterpret_cast<const ulonglong2 *>(&s[el]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const ulonglong2 *>(&s[64 * i + 2 * t]);
     }
     if constexpr (PRE) {  // Decryptor::decrypt: the element is bx + sx * ax (NttArgs::pre_a)
-      const u64 lo = (u64)limb_source(a, l) * N + (u64)row * 256 + el;
-      const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(&a.pre_a[(u64)b * a.src_bstride + lo]);
-      const ulonglong2 k = *reinterpret_cast<const ulonglong2 *>(&a.pre_k[lo]);
-      v.x = csub(mulmod_full<SP>(k.x, x.x, P) + csub(v.x, P.p), P.p);
-      v.y = csub(mulmod_full<SP>(k.y, x.y, P) + csub(v.y, P.p), P.p);
+      ulonglong2 x[4], k[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u64 lo = (u64)limb_source(a, l) * N + (u64)row * 256 + 64 * i + 2 * t;
+        x[i] = *reinterpret_cast<const ulonglong2 *>(&a.pre_a[(u64)b * a.src_bstride + lo]);
+        k[i] = *reinterpret_cast<const ulonglong2 *>(&a.pre_k[lo]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i].x = csub(mulmod_full<SP>(k[i].x, x[i].x, P) + csub(v[i].x, P.p), P.p);
+        v[i].y = csub(mulmod_full<SP>(k[i].y, x[i].y, P) + csub(v[i].y, P.p), P.p);
+      }
     }
-    DBG_RANGE(v.x, P.twop, 4); DBG_RANGE(v.y, P.twop, 4);
-    *reinterpret_cast<ulonglong2 *>(&L[row8_pos(el)]) = v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      DBG_RANGE(v[i].x, P.twop, 4); DBG_RANGE(v[i].y, P.twop, 4);
+      *reinterpret_cast<ulonglong2 *>(&L[row8_pos(64 * i + 2 * t)]) = v[i];
+    }
   }
   wave_lds_sync();
   u64 e[8];
@@ -760,7 +774,7 @@ __device__ __forceinline__ PrimeC load_prime_const(const PrimeC *p) {
   PrimeC P;
   P.p = q[0]; P.twop = q[1]; P.pinv = q[2]; P.r2 = q[3]; P.ninv_m = q[4];
   const u64 w = q[5];
-  P.p1 = (u32)w; P.pad = (u32)(w >> 32);
+  P.p1 = (u32)w; P.n32 = (u32)(w >> 32);
   return P;
 }
 static_assert(sizeof(PrimeC) == 48, "load_prime_const reads six words");

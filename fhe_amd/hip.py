@@ -110,6 +110,7 @@ OP_MUL_RELIN_RESCALE, OP_ROTATE, OP_ROTATE_MIXED, OP_ROTATE_NON_NTT = 1, 2, 3, 4
 TUNE_RELIN_GROUP = 1
 TUNE_NTT_CHUNK = 2
 TUNE_ONEPASS = 3
+TUNE_NTT_STREAMS = 4
 NOALLOC_SCRATCH_BYTES = 256 << 20
 
 

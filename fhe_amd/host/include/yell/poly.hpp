@@ -17,6 +17,8 @@
 #include <numeric>
 #include <stdexcept>
 #include <unordered_map>
+#include <random>
+#include <cstdlib>
 #include <vector>
 
 #include "fhe_hip.h"
@@ -99,17 +101,28 @@ inline void barret_reduction(gT *x, size_t cm) { *x %= params::P[cm]; }
 template <size_t n> struct static_log2 { static constexpr size_t value = 1 + static_log2<n / 2>::value; };
 template <> struct static_log2<1> { static constexpr size_t value = 0; };
 
-// deterministic splitmix64 stream shared by the samplers (the reference's PRNG is not pinned)
+// splitmix64 stream shared by the samplers (the reference's PRNG is not pinned).  The process-wide stream
+// prng::global() and the Gaussian sampler's own stream are seeded from the operating system's entropy source, so two processes
+// never derive the same secret key or encryption randomness.  Reproducible runs (tests, host_roundtrip) set the environment
+// variable FHE_HOST_SEED=<integer> or call prng::reseed(); splitmix64 is a statistical generator, not a cryptographic one:
+// the host mirror's key generation is plumbing for the GPU path, and a deployment plugs in its own sampler.
 struct prng {
   uint64_t state;
-  explicit prng(uint64_t seed = 0x243F6A8885A308D3ull) : state(seed) {}
+  explicit prng(uint64_t seed) : state(seed) {}
+  // 64 bits of OS entropy, or (FHE_HOST_SEED set) a value derived from that seed and the stream's tag
+  static uint64_t fresh_seed(uint64_t tag) {
+    if (const char *e = std::getenv("FHE_HOST_SEED")) return std::strtoull(e, nullptr, 0) * 0x9E3779B97F4A7C15ull + tag;
+    std::random_device rd;
+    return ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ ((uint64_t)rd() << 17);
+  }
+  static void reseed(uint64_t seed) { global().state = seed * 0x9E3779B97F4A7C15ull + 0x243F6A8885A308D3ull; }
   uint64_t next() {
     uint64_t z = (state += 0x9E3779B97F4A7C15ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
   }
-  static prng &global() { static prng g; return g; }
+  static prng &global() { static prng g(fresh_seed(0x243F6A8885A308D3ull)); return g; }
 };
 struct uniform {};
 struct hwt_dist { size_t hwt; explicit hwt_dist(size_t h) : hwt(h) {} };
@@ -117,7 +130,8 @@ struct ZO_dist {};
 // stands for yell::FastGaussianNoise / yell::gaussian: centred binomial of variance 10.5 (sigma ~ 3.24)
 template <class In = uint16_t, class Out = params::value_type, unsigned lu = 2> struct FastGaussianNoise {
   prng rng;
-  FastGaussianNoise(double /*sigma*/ = 3.2, unsigned /*bits*/ = 128, size_t /*samples*/ = 1 << 14, uint64_t seed = 0x13198A2E03707344ull) : rng(seed) {}
+  FastGaussianNoise(double /*sigma*/ = 3.2, unsigned /*bits*/ = 128, size_t /*samples*/ = 1 << 14) : rng(prng::fresh_seed(0x13198A2E03707344ull)) {}
+  FastGaussianNoise(double, unsigned, size_t, uint64_t seed) : rng(seed) {}
 };
 template <class In = uint16_t, class Out = params::value_type, unsigned lu = 2> struct gaussian {
   FastGaussianNoise<In, Out, lu> *fg;

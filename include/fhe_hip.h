@@ -174,6 +174,9 @@ int fhe_hip_mul_relin_rescale_noalloc(fhe_hip_ctx *ctx, uint64_t *out, const uin
 /*   FHE_HIP_TUNE_NTT_CHUNK: limbs per column-pass / row-pass launch pair of fhe_hip_ntt_forward / _backward (0 = the whole call,
  *   the default): with a chunk whose limbs fit the 256 MiB Infinity Cache the second pass reads what the first just wrote. */
 #define FHE_HIP_TUNE_NTT_CHUNK 2
+#define FHE_HIP_TUNE_NTT_STREAMS 4 /* 2 (default): fhe_hip_ntt_forward / _backward at N >= 2^15 with at least two chunks of limbs (chunk =
+                                    * FHE_HIP_TUNE_NTT_CHUNK, default 128) issue the chunks alternately on two library-owned streams forked from
+                                    * and joined to the context's stream, so one chunk's column pass overlaps another's row pass; 1: one stream */
 #define FHE_HIP_TUNE_ONEPASS 3     /* 1 (default): plain NTTs at N = 2^12 .. 2^14 run as one kernel with the limb in LDS; 0: pass pair */
 int fhe_hip_set_tuning(fhe_hip_ctx *ctx, int knob, uint64_t value);
 

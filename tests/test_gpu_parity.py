@@ -51,6 +51,23 @@ def generic_primes(logN, count):
     return np.array(pr, np.uint64), np.array(ps, np.uint64)
 
 
+def generic_primes_below(logN, count, top):
+    """Generic-form primes descending from `top` (exclusive): the carry corners of the word-serial Montgomery steps sit at the
+    upper end of the contract (p just below 2^62), and short primes exercise zero high words."""
+    pr, ps = [], []
+    step = 1 << (logN + 1)
+    p = top - (top - 1) % step
+    while len(pr) < count:
+        p -= step
+        if p % (1 << 32) != 1 and orc.lib.orc_is_prime(p):
+            x = 2
+            while pow(x, (p - 1) // 2, p) != p - 1:
+                x += 1
+            pr.append(p)
+            ps.append(pow(x, (p - 1) >> (logN + 1), p))
+    return np.array(pr, np.uint64), np.array(ps, np.uint64)
+
+
 def rand_poly(o, idx, seed, bound=None):
     rng = np.random.default_rng(seed)
     return np.stack([rng.integers(0, int(o.primes[i]) if bound is None else bound, o.N, dtype=np.uint64) for i in idx])
@@ -129,6 +146,87 @@ def test_ntt_word_edge_patterns(logN, sp):
         d = dev(hi)
         g.ntt_forward(d, idx)
         assert np.array_equal(host(d), want_hi)
+
+
+@pytest.mark.parametrize("top", [1 << 62, (1 << 62) - (1 << 40), 1 << 45, 1 << 33])
+def test_generic_primes_across_the_contract_range(top):
+    """The generic word-serial Montgomery arithmetic (modarith.h:mont_generic) with primes at the top of the contract (just below
+    2^62: every carry word in play), and with short primes (high words small or zero): NTT both ways on corner patterns and on
+    lazy inputs, then a whole multiply + relinearize + rescale and a rotation, against the oracle."""
+    logN, L, K, Li = 12, 3, 2, 3
+    pr, ps = generic_primes_below(logN, L + K, top)
+    o, g = orc.Oracle(logN, L, K, pr, ps), fhe_amd.HipContext(logN, L, K, pr, ps)
+    for m in (0, L + K - 1):
+        p = int(pr[m])
+        x = _word_edge_patterns(p, o.N, 300 + m)
+        idx = [m] * x.shape[0]
+        for inp in (x, x + np.uint64(3 * p)):
+            want = o.ntt_forward(inp.copy(), idx)
+            d = dev(inp)
+            g.ntt_forward(d, idx)
+            assert np.array_equal(host(d), want)
+        want_b = o.ntt_backward(x.copy(), idx)
+        d = dev(x)
+        g.ntt_backward(d, idx)
+        assert np.array_equal(host(d), want_b)
+    sx, ext = o.keygen_sk(seed=41)
+    beta, alpha = o.keygen_mult(sx, seed=42)
+    g.load_mult_key(dev(beta), dev(alpha))
+    c0 = np.stack([rand_poly(o, range(Li), 43), rand_poly(o, range(Li), 44)])
+    c1 = np.stack([rand_poly(o, range(Li), 45), rand_poly(o, range(Li), 46)])
+    out = torch.zeros((1, 2, Li - 1, o.N), dtype=torch.int64, device="cuda")
+    g.mul_relin_rescale(out, dev(c0[None]), dev(c1[None]), Li, batch=1)
+    want = np.stack(o.mul_relin_rescale(c0[0], c0[1], c1[0], c1[1], beta, alpha))
+    assert np.array_equal(host(out)[0], want)
+    gal = 3
+    rkb, rka = o.keygen_rot(sx, ext, gal, seed=47)
+    g.load_rot_key(gal, dev(rkb), dev(rka))
+    rot = torch.zeros((1, 2, Li, o.N), dtype=torch.int64, device="cuda")
+    g.rotate_to(gal, rot, dev(c0[None]), Li, batch=1)
+    assert np.array_equal(host(rot)[0], np.stack(o.rotate(c0[0], c0[1], gal, rkb, rka)))
+    g.close()
+
+
+@pytest.mark.parametrize("logN", [15, 16])
+def test_two_stream_overlapped_ntt_matches_the_oracle_and_one_stream(logN):
+    """fhe_hip_ntt_forward / _backward at N >= 2^15 issue their chunks alternately on two library-owned streams
+    (FHE_HIP_TUNE_NTT_STREAMS).  With a chunk of 2 limbs the 7-limb call below takes that path (four chunks, the last one short):
+    bit-exact against the oracle both ways, from device and from host memory; then the default chunk (128 limbs) on 300 limbs
+    against the one-stream result, with other work queued on the caller's stream before and after the call (fork / join)."""
+    o, g = ctx_pair(logN, 3, 2)
+    idx = [0, 1, 2, 3, 4, 2, 0]
+    x = rand_poly(o, idx, 700 + logN)
+    want = o.ntt_forward(x.copy(), idx)
+    g.set_tuning(fhe_amd.hip.TUNE_NTT_CHUNK, 2)
+    try:
+        d = dev(x)
+        g.ntt_forward(d, idx)
+        assert np.array_equal(host(d), want)
+        g.ntt_backward(d, idx)
+        assert np.array_equal(host(d), x)
+        h = x.copy()
+        g.ntt_forward(h, idx)  # host buffers: staged copies before the fork and after the join
+        assert np.array_equal(h, want)
+    finally:
+        g.set_tuning(fhe_amd.hip.TUNE_NTT_CHUNK, 0)
+    n = 300
+    idx = np.arange(n, dtype=np.uint32) % 5
+    gen = torch.Generator(device="cuda").manual_seed(logN)
+    src = torch.randint(0, 1 << 61, (n, o.N), dtype=torch.int64, device="cuda", generator=gen)
+    a = src.clone() + 0  # produced on the caller's stream right before the call
+    g.ntt_forward(a, idx)
+    a_plus = a + 1       # consumed on the caller's stream right after it
+    g.set_tuning(fhe_amd.hip.TUNE_NTT_STREAMS, 1)
+    try:
+        b = src.clone()
+        g.ntt_forward(b, idx)
+    finally:
+        g.set_tuning(fhe_amd.hip.TUNE_NTT_STREAMS, 2)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a_plus, b + 1)
+    g.ntt_backward(a, idx)
+    torch.cuda.synchronize()
+    assert torch.equal(a, src)
 
 
 def test_pointwise_word_edge_patterns():
@@ -652,6 +750,14 @@ def test_rotate_out_of_place_matches_in_place_and_oracle(logN, L, K, Li):
     with pytest.raises(fhe_amd.FheHipError) as e:
         g.rotate_to(3, src, src, Li, batch=B)
     assert e.value.code == -1
+    # partially overlapping ranges are refused as well (out = in + one half: the last kernel would gather what it overwrites)
+    big = torch.zeros((B * 2 * Li + Li, o.N), dtype=torch.int64, device="cuda")
+    with pytest.raises(fhe_amd.FheHipError) as e:
+        g.rotate_to(3, big[Li:], big[:B * 2 * Li], Li, batch=B)
+    assert e.value.code == -1 and "overlap" in str(e.value)
+    with pytest.raises(fhe_amd.FheHipError) as e:  # the limb count is validated before the galois == 0 copy
+        g.rotate_to(0, out, dev(ct), o.L + 1, batch=0)
+    assert e.value.code == -2
 
 
 def test_full_size_rotation_and_multiplication_decrypt_to_the_right_plaintext():

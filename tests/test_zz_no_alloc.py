@@ -94,6 +94,36 @@ def test_noalloc_rejects_what_does_not_fit_and_host_buffers():
     g.close()
 
 
+def test_noalloc_exact_fit_of_the_documented_budget():
+    """batch * (9 Li - 2) * N * 8 == FHE_HIP_NOALLOC_SCRATCH_BYTES exactly (N = 2^16, Li = 2, batch 32: 512 limbs of 512 KiB) is
+    admitted and correct: the entry point's precheck and the relinearisation's own sizing use one formula.  One op more is refused
+    before anything runs."""
+    logN, L, K, Li, B = 16, 2, 1, 2, 32
+    pr, ps = orc.gen_primes(logN, L + K)
+    g = fhe_amd.HipContext(logN, L, K, pr, ps)
+    N = 1 << logN
+    assert B * (9 * Li - 2) * N * 8 == 256 << 20
+    gen = torch.Generator(device="cuda").manual_seed(80)
+    g.load_mult_key(_rand((L, L, N), gen), _rand((L, L, N), gen))
+    c0, c1 = _rand((B + 1, 2, Li, N), gen), _rand((B + 1, 2, Li, N), gen)
+    want = torch.zeros((B, 2, Li - 1, N), dtype=torch.int64, device="cuda")
+    g.mul_relin_rescale(want, c0[:B].contiguous(), c1[:B].contiguous(), Li, batch=B)
+    got = torch.full_like(want, -1)
+    g.mul_relin_rescale_noalloc(got, c0[:B].contiguous(), c1[:B].contiguous(), Li, batch=B)
+    g.sync()
+    assert torch.equal(got, want)
+    out = torch.full((B + 1, 2, Li - 1, N), 7, dtype=torch.int64, device="cuda")
+    with pytest.raises(fhe_amd.FheHipError) as e:
+        g.mul_relin_rescale_noalloc(out, c0, c1, Li, batch=B + 1)
+    assert e.value.code == -2
+    assert bool((out == 7).all())
+    # the allocating entry point is untouched by the refusal (its workspaces were put back)
+    g.mul_relin_rescale(got, c0[:B].contiguous(), c1[:B].contiguous(), Li, batch=B)
+    g.sync()
+    assert torch.equal(got, want)
+    g.close()
+
+
 def test_noalloc_entry_point_can_be_captured_in_a_hip_graph_and_replayed():
     """What the entry point is for: a caller under stream capture.  The call is captured on a side stream (nothing executes, no
     allocation, event or synchronisation is attempted inside it), and replays give the allocating entry point's bits, also

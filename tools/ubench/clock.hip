@@ -33,7 +33,7 @@ __global__ void k_add(u64* out, u64* stamps, int iters) {
 int main() {
   const int grid = 256 * 8, block = 256;
   u64 *out, *st; hipMalloc(&out, (size_t)grid * block * 8); hipMalloc(&st, grid * 16);
-  PrimeC P; P.p = ((u64)((1u << 30) - 35) << 32) + 1; P.twop = 2 * P.p; P.p1 = (u32)(P.p >> 32); P.r2 = 12345; P.pinv = 1; P.ninv_m = 1; P.pad = 0;
+  PrimeC P; P.p = ((u64)((1u << 30) - 35) << 32) + 1; P.twop = 2 * P.p; P.p1 = (u32)(P.p >> 32); P.r2 = 12345; P.pinv = 1; P.ninv_m = 1; P.n32 = 0u - (u32)P.pinv;
   std::vector<u64> h(grid * 2);
   for (int rep = 0; rep < 3; ++rep) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

@@ -89,7 +89,7 @@ template <bool DPP> __global__ __launch_bounds__(256) void k(u64 *out, const u64
 
 int main() {
   PrimeC P; const u64 p = (((1ull << 30) - 35) << 32) + 1;  // an SP-form modulus (primality is irrelevant to the timing)
-  P.p = p; P.twop = 2 * p; P.pinv = 0; P.r2 = 1; P.ninv_m = 1; P.p1 = (u32)(p >> 32); P.pad = 0;
+  P.p = p; P.twop = 2 * p; P.pinv = 0; P.r2 = 1; P.ninv_m = 1; P.p1 = (u32)(p >> 32); P.n32 = 0u - (u32)P.pinv;
   u64 *out, *tw; CHECK(hipMalloc(&out, 256 * 8 * 256 * 8)); CHECK(hipMalloc(&tw, 1024 * 8));
   u64 h[1024]; for (int i = 0; i < 1024; ++i) h[i] = (0x9E3779B97F4A7C15ull * (i + 1)) % p;
   CHECK(hipMemcpy(tw, h, sizeof(h), hipMemcpyHostToDevice));
