@@ -418,6 +418,21 @@ int dev_conv_to_special(fhe_hip_ctx *c, u64 *rop, u32 rop_limbs, u32 rop_off, co
   else { if (c->sp) LAUNCH(c, "bconv_modup", (bconv_kernel<true, false>), grid, dim3(PW_THREADS), a); else LAUNCH(c, "bconv_modup", (bconv_kernel<false, false>), grid, dim3(PW_THREADS), a); }
   return FHE_HIP_OK;
 }
+// approx_convert_to_special_basis (src/base_converter.cpp:276-295), ONE special target k: rop = [b][N]
+int dev_conv_to_special_one(fhe_hip_ctx *c, u64 *rop, const u64 *op, u32 Li, u32 k, u32 batch) {
+  BconvArgs a;
+  a.out = rop; a.src = op;
+  a.inv_m = c->d_hat_qj_inv_m + (size_t)(Li - 2) * c->L;
+  a.hat_m = c->d_hat_qj_pi_m + ((size_t)(Li - 2) * c->K + k) * c->L;   // row k of the Li-2 table
+  a.primes = c->d_primes;
+  a.nsrc = Li; a.src_first = 0; a.src_limbs = Li; a.src_off = 0;
+  a.tgt_first = c->L + k; a.out_limbs = 1; a.out_off = 0; a.hat_stride = c->L; a.ntgt = 1;
+  a.N = c->N;
+  const dim3 grid((unsigned)(c->N / PW_THREADS), 1, batch);
+  if (c->sp) LAUNCH(c, "bconv_modup", (bconv_kernel<true, false>), grid, dim3(PW_THREADS), a);
+  else LAUNCH(c, "bconv_modup", (bconv_kernel<false, false>), grid, dim3(PW_THREADS), a);
+  return FHE_HIP_OK;
+}
 // neg_approx_convert_to_normal_basis for j < L0: special limbs (power basis) at limb offset sp_off of op
 int dev_conv_to_normal(fhe_hip_ctx *c, u64 *rop, u32 L0, const u64 *op, u32 op_limbs, u32 sp_off, u32 batch, bool pre_scaled = false) {
   BconvArgs a;
@@ -1016,6 +1031,57 @@ int fhe_hip_conv_to_normal(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *sp, ui
   TRY(st.out(rop, batch * L0 * c->N * 8, &drop, false));
   TRY(dev_conv_to_normal(c, drop, L0, dsp, c->K, 0, (u32)batch));
   return st.finish();
+  } catch (...) { return abi_exception(); }
+}
+
+int fhe_hip_conv_to_special(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t Li, uint32_t sp_index, size_t batch, int mem_kind) {
+  try {
+  TRY(check_ctx(c));
+  if (!rop || !op) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (Li > c->L) FAIL(c, FHE_HIP_ERR_RANGE, "Only support mod up from normal primes");
+  if (Li <= 1) FAIL(c, FHE_HIP_ERR_RANGE, "nmoduli <= 1");  // base_converter.cpp:284-285
+  if (sp_index >= c->K) FAIL(c, FHE_HIP_ERR_RANGE, "special prime index out of range");
+  if (batch == 0) return FHE_HIP_OK;
+  Staged st(c, mem_kind);
+  const u64 *dop = nullptr; u64 *drop = nullptr;
+  TRY(st.in(op, batch * Li * c->N * 8, &dop));
+  TRY(st.out(rop, batch * c->N * 8, &drop, false));
+  TRY(dev_conv_to_special_one(c, drop, dop, Li, sp_index, (u32)batch));
+  return st.finish();
+  } catch (...) { return abi_exception(); }
+}
+
+int fhe_hip_mem_alloc(fhe_hip_ctx *c, uint64_t **dptr, size_t words) {
+  try {
+  TRY(check_ctx(c));
+  if (!dptr) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  *dptr = nullptr;
+  HIPCHK(c, hipMalloc((void **)dptr, (words ? words : 1) * sizeof(uint64_t)));
+  return FHE_HIP_OK;
+  } catch (...) { return abi_exception(); }
+}
+int fhe_hip_mem_free(fhe_hip_ctx *c, uint64_t *dptr) {
+  try {
+  TRY(check_ctx(c));
+  if (!dptr) return FHE_HIP_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // work enqueued on the context's stream may still use the block
+  HIPCHK(c, hipFree(dptr));
+  return FHE_HIP_OK;
+  } catch (...) { return abi_exception(); }
+}
+int fhe_hip_mem_copy(fhe_hip_ctx *c, void *dst, const void *src, size_t bytes, int direction) {
+  try {
+  TRY(check_ctx(c));
+  if (bytes == 0) return FHE_HIP_OK;
+  if (!dst || !src) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  hipMemcpyKind kind;
+  if (direction == FHE_HIP_COPY_H2D) kind = hipMemcpyHostToDevice;
+  else if (direction == FHE_HIP_COPY_D2H) kind = hipMemcpyDeviceToHost;
+  else if (direction == FHE_HIP_COPY_D2D) kind = hipMemcpyDeviceToDevice;
+  else FAIL(c, FHE_HIP_ERR_ARG, "unknown copy direction");
+  HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(dst, src, bytes, kind, c->stream)));
+  if (direction != FHE_HIP_COPY_D2D) HIPCHK(c, hipStreamSynchronize(c->stream));  // the host buffer is the caller's again on return
+  return FHE_HIP_OK;
   } catch (...) { return abi_exception(); }
 }
 

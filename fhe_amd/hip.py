@@ -68,6 +68,10 @@ def load_library():
         "fhe_hip_mod_down": (i, [vp, vp, vp, u32, sz, i]),
         "fhe_hip_rescale": (i, [vp, vp, vp, u32, sz, i]),
         "fhe_hip_conv_to_normal": (i, [vp, vp, vp, u32, sz, i]),
+        "fhe_hip_conv_to_special": (i, [vp, vp, vp, u32, u32, sz, i]),
+        "fhe_hip_mem_alloc": (i, [vp, C.POINTER(vp), sz]),
+        "fhe_hip_mem_free": (i, [vp, vp]),
+        "fhe_hip_mem_copy": (i, [vp, vp, vp, sz, i]),
         "fhe_hip_load_mult_key": (i, [vp, vp, vp, i]),
         "fhe_hip_load_rot_key": (i, [vp, u64, vp, vp, i]),
         "fhe_hip_add": (i, [vp, vp, vp, u32, sz, i]),
@@ -105,6 +109,7 @@ EXPORTED_SYMBOLS = [
     "fhe_hip_add", "fhe_hip_multiply_plain", "fhe_hip_cross_mult", "fhe_hip_relin_only", "fhe_hip_relinearize",
     "fhe_hip_mul_relin_rescale", "fhe_hip_rotate", "fhe_hip_rotate_non_ntt", "fhe_hip_load_mixed_rot_key", "fhe_hip_rotate_mixed", "fhe_hip_decrypt", "fhe_hip_encrypt", "fhe_hip_profile_enable", "fhe_hip_profile_reset",
     "fhe_hip_profile_get", "fhe_hip_batch_run", "fhe_hip_conv_to_normal", "fhe_hip_mul_relin_rescale_noalloc", "fhe_hip_set_tuning", "fhe_hip_debug_violations", "fhe_hip_rotate_to",
+    "fhe_hip_conv_to_special", "fhe_hip_mem_alloc", "fhe_hip_mem_free", "fhe_hip_mem_copy",
 ]
 OP_MUL_RELIN_RESCALE, OP_ROTATE, OP_ROTATE_MIXED, OP_ROTATE_NON_NTT = 1, 2, 3, 4
 TUNE_RELIN_GROUP = 1
@@ -239,6 +244,14 @@ class HipContext:
         (r, o), kind = _same_kind(rop, sp)
         _need(rop=(rop, batch * L0 * self.N), sp=(sp, batch * self.K * self.N))
         self._chk(self.lib.fhe_hip_conv_to_normal(self.h, r, o, L0, batch, kind))
+        return rop
+
+    def conv_to_special(self, rop, op, Li, sp_index, batch=1):
+        """BaseConverter::approx_convert_to_special_basis for one special prime (src/base_converter.cpp:276-295):
+        op = [batch][Li][N] power basis -> rop = [batch][N] under P[L + sp_index]."""
+        (r, o), kind = _same_kind(rop, op)
+        _need(rop=(rop, batch * self.N), op=(op, batch * Li * self.N))
+        self._chk(self.lib.fhe_hip_conv_to_special(self.h, r, o, Li, sp_index, batch, kind))
         return rop
 
     # ---- keys -------------------------------------------------------------------------------

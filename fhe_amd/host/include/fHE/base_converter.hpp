@@ -33,9 +33,9 @@ struct BaseConverter {
   // single-target conversions (:276-311), expressed through the batched entry points
   void approx_convert_to_special_basis(T *rop, context::poly_t const &op, const size_t sp_moduli_index) const {
     if (!rop) return;
-    context::poly_t ext(op.moduli_count() + context::nr_sp_primes);
-    if (!approximated_mod_up(&ext, op)) return;
-    std::memcpy(rop, ext.cptr_at(op.moduli_count() + sp_moduli_index), sizeof(T) * context::degree);
+    const size_t n = op.moduli_count();
+    if (n <= 1) throw std::invalid_argument("nmoduli <= 1");   // src/base_converter.cpp:284-285
+    yell::check(fhe_hip_conv_to_special(yell::runtime::get().ctx, rop, op.cptr_at(0), (uint32_t)n, (uint32_t)sp_moduli_index, 1, FHE_HIP_MEM_HOST), "conv_to_special");
   }
   // op = the K special limbs in the power basis -> -conv_{P -> q_j}(op) for one normal modulus j (:297-311)
   void neg_approx_convert_to_normal_basis(T *rop, context::poly_t const &op, const size_t nrl_moduli_index) const {

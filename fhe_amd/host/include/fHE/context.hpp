@@ -60,6 +60,7 @@ class Context {
     default_primes(logN, L + K, primes_, psi_);
     int rc = fhe_hip_ctx_create(&ctx_, logN, L, K, primes_.data(), psi_.data(), device);
     if (rc != FHE_HIP_OK) throw std::runtime_error(std::string("fhe_hip_ctx_create: ") + fhe_hip_last_error(nullptr));
+    yell::block_pool::get().open(ctx_);
     activate();
   }
   Context(Context const &) = delete;
@@ -67,6 +68,7 @@ class Context {
   ~Context() {
     yell::runtime::get().loaded.erase(ctx_);
     if (yell::runtime::get().ctx == ctx_) yell::runtime::get().ctx = nullptr;
+    yell::block_pool::get().drain(ctx_);  // polynomials that outlive the context return their blocks to a closed pool: freed at once
     fhe_hip_ctx_destroy(ctx_);
   }
   void activate() {

@@ -20,10 +20,10 @@ struct Decryptor {
     if (!rop) return false;
     rop->resize_moduli_count(Li);
     if (Li == 0) return true;
-    std::vector<detail::word> halves(2 * Li * n);
-    std::copy(ct.bx.cptr_at(0), ct.bx.cptr_at(0) + Li * n, halves.begin());
-    std::copy(ct.ax.cptr_at(0), ct.ax.cptr_at(0) + Li * n, halves.begin() + Li * n);
-    return fhe_hip_decrypt(yell::runtime::get().ctx, rop->ptr_at(0), halves.data(), sk.sx.cptr_at(0), (uint32_t)Li, 1, FHE_HIP_MEM_HOST) == FHE_HIP_OK;
+    auto out = std::make_shared<yell::dev_block>(yell::runtime::get().ctx, Li * n);
+    if (fhe_hip_decrypt(yell::runtime::get().ctx, out->p, ct.device_parts(), sk.sx.cdev(), (uint32_t)Li, 1, FHE_HIP_MEM_DEVICE) != FHE_HIP_OK) return false;
+    rop->adopt(out, 0, Li);   // comes to the host when the caller reads it
+    return true;
   }
   bool decrypt(std::vector<std::complex<double>> *rop, Cipher const &ct, SK const &sk) const { return decrypt_then_decode(rop, ct, sk); }
   bool decrypt(std::vector<double> *rop, Cipher const &ct, SK const &sk) const { return decrypt_then_decode(rop, ct, sk); }

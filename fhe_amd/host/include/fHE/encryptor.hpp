@@ -24,11 +24,12 @@ struct Encryptor {
       detail::word *dst = e0m.ptr_at(m);
       for (size_t d = 0; d < n; ++d) { const detail::word t = dst[d] + src[d] % p; dst[d] = t >= p ? t - p : t; }
     }
-    std::vector<detail::word> ct(2 * Li * n);
-    if (fhe_hip_encrypt(yell::runtime::get().ctx, ct.data(), u.cptr_at(0), e0m.cptr_at(0), e1.cptr_at(0), pk.bx.cptr_at(0), pk.ax.cptr_at(0),
-                        (uint32_t)Li, 1, FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
-    std::copy(ct.begin(), ct.begin() + Li * n, rop->bx.ptr_at(0));
-    std::copy(ct.begin() + Li * n, ct.end(), rop->ax.ptr_at(0));
+    // the result is written where it will live: one device block [half][limb][N] that the ciphertext's halves then view;
+    // the public key's device copy is uploaded once and stays with the key
+    auto out = std::make_shared<yell::dev_block>(yell::runtime::get().ctx, 2 * Li * n);
+    if (fhe_hip_encrypt(yell::runtime::get().ctx, out->p, u.cdev(), e0m.cdev(), e1.cdev(), pk.bx.cdev(), pk.ax.cdev(),
+                        (uint32_t)Li, 1, FHE_HIP_MEM_DEVICE) != FHE_HIP_OK) return false;
+    rop->adopt_device(out, 0, Li);
     u.clear(); e0m.clear(); e1.clear();
     return true;
   }

@@ -67,20 +67,40 @@ struct Evaluator {
     return true;
   }
 
+  using block = yell::dev_block;
+  static yell::dev_block_ptr new_block(size_t words) { return std::make_shared<block>(ctx(), words); }
+
+  // B ciphertexts of Li limbs as ONE device operand [ct][half][limb][N].  Ciphertexts that an earlier batched call left as
+  // consecutive views of one block are used where they lie; otherwise they are brought together (device-to-device, or
+  // uploaded if they live on the host) and stay views of the new block.
+  // The block is returned with the pointer: the caller holds it until its device call is enqueued (gathering a second
+  // operand may move polynomials out of the first one's block, which must not be freed under the pointer).
+  template <class CipherPtr> static std::pair<const T *, yell::dev_block_ptr> device_batch(std::vector<CipherPtr> const &cts, size_t Li) {
+    const size_t w = 2 * Li * context::degree;
+    const T *base = cts[0]->device_parts();
+    bool together = true;
+    for (size_t b = 1; b < cts.size() && together; ++b) {
+      Cipher const &c = *cts[b];
+      together = c.bx.on_device() && c.ax.on_device() && c.bx.block() == cts[0]->bx.block() && c.bx.block_offset() == cts[0]->bx.block_offset() + b * w &&
+                 c.ax.block() == c.bx.block() && c.ax.block_offset() == c.bx.block_offset() + w / 2;
+    }
+    if (together) return {base, cts[0]->bx.block()};
+    auto blk = new_block(cts.size() * w);
+    for (size_t b = 0; b < cts.size(); ++b) { cts[b]->bx.relocate(blk, b * w); cts[b]->ax.relocate(blk, b * w + w / 2); }
+    return {blk->p, blk};
+  }
+
   bool rotate_with(Cipher *rop, RotKey const &rkey, bool non_ntt) const {
     if (!rop || !canonical_or_complain(rop, "rotate")) return false;
     if (rkey.galois == 0) return true;
-    const size_t Li = rop->moduli_count(), N = context::degree, limbs = Li * N;
+    const size_t Li = rop->moduli_count(), N = context::degree;
     if (Li > context::nr_ctxt_moduli) throw std::invalid_argument("Too many moduli.");
     if (Li <= 1) throw std::invalid_argument("nmoduli <= 1");
     if (!ensure_rot_key(rkey)) return false;
-    std::vector<T> ct(2 * limbs);
-    pack(ct, 0, rop->bx, Li); pack(ct, limbs, rop->ax, Li);
-    const int rc = non_ntt ? fhe_hip_rotate_non_ntt(ctx(), rkey.galois, ct.data(), (uint32_t)Li, 1, FHE_HIP_MEM_HOST)
-                           : fhe_hip_rotate(ctx(), rkey.galois, ct.data(), (uint32_t)Li, 1, FHE_HIP_MEM_HOST);
-    if (rc != FHE_HIP_OK) return false;
-    std::memcpy(rop->bx.ptr_at(0), ct.data(), limbs * sizeof(T));
-    std::memcpy(rop->ax.ptr_at(0), ct.data() + limbs, limbs * sizeof(T));
+    if (non_ntt) return fhe_hip_rotate_non_ntt(ctx(), rkey.galois, rop->device_parts_mut(), (uint32_t)Li, 1, FHE_HIP_MEM_DEVICE) == FHE_HIP_OK;
+    auto out = new_block(2 * Li * N);   // out of place on the device: no copy back over the input
+    if (fhe_hip_rotate_to(ctx(), rkey.galois, out->p, rop->device_parts(), (uint32_t)Li, 1, FHE_HIP_MEM_DEVICE) != FHE_HIP_OK) return false;
+    rop->adopt_device(out, 0, Li);
     return true;
   }
 
@@ -93,11 +113,11 @@ struct Evaluator {
     if (rop->moduli_count() != c1.moduli_count()) { std::cerr << "Can not add_inplace." << std::endl; return false; }
     if (!rop->canonical() && c1.canonical()) { std::cerr << "Can not add_inplace" << std::endl; return false; }
     const uint32_t n = (uint32_t)rop->moduli_count();
-    bool ok = fhe_hip_add(ctx(), rop->bx.ptr_at(0), c1.bx.cptr_at(0), n, 1, FHE_HIP_MEM_HOST) == FHE_HIP_OK &&
-              fhe_hip_add(ctx(), rop->ax.ptr_at(0), c1.ax.cptr_at(0), n, 1, FHE_HIP_MEM_HOST) == FHE_HIP_OK;
+    bool ok = fhe_hip_add(ctx(), rop->bx.dev(), c1.bx.cdev(), n, 1, FHE_HIP_MEM_DEVICE) == FHE_HIP_OK &&
+              fhe_hip_add(ctx(), rop->ax.dev(), c1.ax.cdev(), n, 1, FHE_HIP_MEM_DEVICE) == FHE_HIP_OK;
     if (!c1.canonical()) {
       if (rop->canonical()) rop->mul_aux = std::make_shared<context::poly_t>(*c1.mul_aux);
-      else ok = ok && fhe_hip_add(ctx(), rop->mul_aux->ptr_at(0), c1.mul_aux->cptr_at(0), n, 1, FHE_HIP_MEM_HOST) == FHE_HIP_OK;
+      else ok = ok && fhe_hip_add(ctx(), rop->mul_aux->dev(), c1.mul_aux->cdev(), n, 1, FHE_HIP_MEM_DEVICE) == FHE_HIP_OK;
     }
     if (rop->scale() == 1.) rop->scale(c1.scale());
     return ok;
@@ -108,26 +128,20 @@ struct Evaluator {
     if (rop->moduli_count() != c1.moduli_count() || !(rop->canonical() && c1.canonical())) { std::cerr << "Can not multiply_inplace" << std::endl; return false; }
     const size_t Li = rop->moduli_count(), N = context::degree, limbs = Li * N;
     const double new_scale = rop->scale() / yell::params::P[Li - 1] * c1.scale();
-    std::vector<T> in0(2 * limbs), in1(2 * limbs), out(3 * limbs);
-    pack(in0, 0, rop->bx, Li); pack(in0, limbs, rop->ax, Li); pack(in1, 0, c1.bx, Li); pack(in1, limbs, c1.ax, Li);
-    if (fhe_hip_cross_mult(ctx(), out.data(), in0.data(), in1.data(), (uint32_t)Li, 1, FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
-    std::memcpy(rop->bx.ptr_at(0), out.data(), limbs * sizeof(T));
-    std::memcpy(rop->ax.ptr_at(0), out.data() + limbs, limbs * sizeof(T));
-    rop->mul_aux = std::make_shared<context::poly_t>(Li);
-    std::memcpy(rop->mul_aux->ptr_at(0), out.data() + 2 * limbs, limbs * sizeof(T));
+    auto out = new_block(3 * limbs);
+    if (fhe_hip_cross_mult(ctx(), out->p, rop->device_parts(), c1.device_parts(), (uint32_t)Li, 1, FHE_HIP_MEM_DEVICE) != FHE_HIP_OK) return false;
+    rop->adopt_device(out, 0, Li);
+    rop->mul_aux = std::make_shared<context::poly_t>(0);
+    rop->mul_aux->adopt(out, 2 * limbs, Li);   // (bx, ax, mul_aux) stay one [3][limb][N] operand for relinearize
     rop->scale(new_scale);
     return true;
   }
 
   bool multiply_plain(Cipher *rop, context::poly_t const &p, const double plain_scale = -1) const {  // evaluator.cpp:88-111
     if (!rop) return false;
-    const size_t nm = p.moduli_count(), N = context::degree;
+    const size_t nm = p.moduli_count();
     if (rop->moduli_count() != nm) return false;
-    std::vector<T> ct(2 * nm * N);
-    pack(ct, 0, rop->bx, nm); pack(ct, nm * N, rop->ax, nm);
-    if (fhe_hip_multiply_plain(ctx(), ct.data(), p.cptr_at(0), (uint32_t)nm, 1, FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
-    std::memcpy(rop->bx.ptr_at(0), ct.data(), nm * N * sizeof(T));
-    std::memcpy(rop->ax.ptr_at(0), ct.data() + nm * N, nm * N * sizeof(T));
+    if (fhe_hip_multiply_plain(ctx(), rop->device_parts_mut(), p.cdev(), (uint32_t)nm, 1, FHE_HIP_MEM_DEVICE) != FHE_HIP_OK) return false;
     if (plain_scale > 0.) rop->scale(rop->scale() * plain_scale);
     return true;
   }
@@ -135,34 +149,55 @@ struct Evaluator {
   bool relinearize(Cipher *rop, MultKey const &mkey) const {  // Impl::relinerize_inplace (relin + rescale), evaluator.cpp:599-619
     if (!rop) return false;
     if (rop->canonical()) return false;
-    const size_t Li = rop->moduli_count(), N = context::degree, limbs = Li * N;
+    const size_t Li = rop->moduli_count(), N = context::degree;
     if (Li < 2 || !ensure_mult_key(mkey)) return false;
-    std::vector<T> in(3 * limbs), out(2 * (Li - 1) * N);
-    pack(in, 0, rop->bx, Li); pack(in, limbs, rop->ax, Li); pack(in, 2 * limbs, *rop->mul_aux, Li);
-    if (fhe_hip_relinearize(ctx(), out.data(), in.data(), (uint32_t)Li, 1, FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
-    const double s = rop->scale();
-    Cipher tmp(Li - 1);
-    std::memcpy(tmp.bx.ptr_at(0), out.data(), (Li - 1) * N * sizeof(T));
-    std::memcpy(tmp.ax.ptr_at(0), out.data() + (Li - 1) * N, (Li - 1) * N * sizeof(T));
-    rop->bx = std::move(tmp.bx); rop->ax = std::move(tmp.ax); rop->mul_aux = nullptr;
-    rop->scale(s);
+    auto out = new_block(2 * (Li - 1) * N);
+    if (fhe_hip_relinearize(ctx(), out->p, rop->device_parts(true), (uint32_t)Li, 1, FHE_HIP_MEM_DEVICE) != FHE_HIP_OK) return false;
+    rop->adopt_device(out, 0, Li - 1);
     return true;
   }
 
   bool multiply_and_relin(Cipher *rop, Cipher const &c1, MultKey const &mkey) const {  // evaluator.cpp:119-126, one fused device call
-    if (!rop) return false;
-    if (rop->moduli_count() != c1.moduli_count() || !(rop->canonical() && c1.canonical())) { std::cerr << "Can not multiply_inplace" << std::endl; return false; }
-    const size_t Li = rop->moduli_count(), N = context::degree, limbs = Li * N;
+    std::vector<Cipher *> rops{rop};
+    std::vector<Cipher const *> c1s{&c1};
+    return rop && multiply_and_relin(rops, c1s, mkey);
+  }
+
+  //! Batched form (no counterpart in the reference, which handles one ciphertext per call): rops[b] <- rops[b] * c1s[b],
+  //! relinearised and rescaled, all in ONE device call over [ct][half][limb][N]; the results are views of one block, so
+  //! a following batched call on the same ciphertexts finds its operand already in place.
+  bool multiply_and_relin(std::vector<Cipher *> const &rops, std::vector<Cipher const *> const &c1s, MultKey const &mkey) const {
+    if (rops.empty() || rops.size() != c1s.size()) return false;
+    const size_t B = rops.size(), Li = rops[0] ? rops[0]->moduli_count() : 0, N = context::degree;
+    for (size_t b = 0; b < B; ++b) {
+      if (!rops[b] || !c1s[b]) return false;
+      if (rops[b]->moduli_count() != Li || c1s[b]->moduli_count() != Li || !(rops[b]->canonical() && c1s[b]->canonical())) { std::cerr << "Can not multiply_inplace" << std::endl; return false; }
+    }
     if (Li < 2 || !ensure_mult_key(mkey)) return false;
-    const double new_scale = rop->scale() / yell::params::P[Li - 1] * c1.scale();
-    std::vector<T> in0(2 * limbs), in1(2 * limbs), out(2 * (Li - 1) * N);
-    pack(in0, 0, rop->bx, Li); pack(in0, limbs, rop->ax, Li); pack(in1, 0, c1.bx, Li); pack(in1, limbs, c1.ax, Li);
-    if (fhe_hip_mul_relin_rescale(ctx(), out.data(), in0.data(), in1.data(), (uint32_t)Li, 1, FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
-    Cipher tmp(Li - 1);
-    std::memcpy(tmp.bx.ptr_at(0), out.data(), (Li - 1) * N * sizeof(T));
-    std::memcpy(tmp.ax.ptr_at(0), out.data() + (Li - 1) * N, (Li - 1) * N * sizeof(T));
-    rop->bx = std::move(tmp.bx); rop->ax = std::move(tmp.ax); rop->mul_aux = nullptr;
-    rop->scale(new_scale);
+    const auto in0 = device_batch(rops, Li), in1 = device_batch(c1s, Li);
+    auto out = new_block(B * 2 * (Li - 1) * N);
+    if (fhe_hip_mul_relin_rescale(ctx(), out->p, in0.first, in1.first, (uint32_t)Li, B, FHE_HIP_MEM_DEVICE) != FHE_HIP_OK) return false;
+    for (size_t b = 0; b < B; ++b) {
+      const double new_scale = rops[b]->scale() / yell::params::P[Li - 1] * c1s[b]->scale();
+      rops[b]->adopt_device(out, b * 2 * (Li - 1) * N, Li - 1);
+      rops[b]->scale(new_scale);
+    }
+    return true;
+  }
+
+  //! Batched rotation with one key (same remark): rops[b] <- rotate(rops[b]) in ONE device call.
+  bool rotate_slots(std::vector<Cipher *> const &rops, RotKey const &rkey) const {
+    if (rops.empty()) return false;
+    const size_t B = rops.size(), Li = rops[0] ? rops[0]->moduli_count() : 0, N = context::degree;
+    for (size_t b = 0; b < B; ++b) if (!rops[b] || rops[b]->moduli_count() != Li || !canonical_or_complain(rops[b], "rotate")) return false;
+    if (rkey.galois == 0) return true;
+    if (Li > context::nr_ctxt_moduli) throw std::invalid_argument("Too many moduli.");
+    if (Li <= 1) throw std::invalid_argument("nmoduli <= 1");
+    if (!ensure_rot_key(rkey)) return false;
+    const auto in = device_batch(rops, Li);
+    auto out = new_block(B * 2 * Li * N);
+    if (fhe_hip_rotate_to(ctx(), rkey.galois, out->p, in.first, (uint32_t)Li, B, FHE_HIP_MEM_DEVICE) != FHE_HIP_OK) return false;
+    for (size_t b = 0; b < B; ++b) rops[b]->adopt_device(out, b * 2 * Li * N, Li);
     return true;
   }
 
@@ -176,14 +211,9 @@ struct Evaluator {
   bool rotate_slots(Cipher *rop, MixedRotKey const &rkey) const {
     if (!rop || !canonical_or_complain(rop, "rotate")) return false;
     if (rkey.galois == 0) return true;
-    const size_t Li = rop->moduli_count(), N = context::degree, limbs = Li * N;
+    const size_t Li = rop->moduli_count();
     if (!ensure_mixed_key(rkey)) return false;
-    std::vector<T> ct(2 * limbs);
-    pack(ct, 0, rop->bx, Li); pack(ct, limbs, rop->ax, Li);
-    if (fhe_hip_rotate_mixed(ctx(), rkey.galois, ct.data(), (uint32_t)Li, 1, FHE_HIP_MEM_HOST) != FHE_HIP_OK) return false;
-    std::memcpy(rop->bx.ptr_at(0), ct.data(), limbs * sizeof(T));
-    std::memcpy(rop->ax.ptr_at(0), ct.data() + limbs, limbs * sizeof(T));
-    return true;
+    return fhe_hip_rotate_mixed(ctx(), rkey.galois, rop->device_parts_mut(), (uint32_t)Li, 1, FHE_HIP_MEM_DEVICE) == FHE_HIP_OK;
   }
 
   //! Rotation by an arbitrary offset (reference src/evaluator.cpp:158-208): offset > 0 rotates left by offset slots, offset < 0

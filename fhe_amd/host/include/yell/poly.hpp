@@ -138,13 +138,83 @@ template <class In = uint16_t, class Out = params::value_type, unsigned lu = 2> 
   explicit gaussian(FastGaussianNoise<In, Out, lu> *p) : fg(p) {}
 };
 
-// limb-major polynomial [nmoduli][degree]; limb k lives under the global modulus index k
+// A block of device memory shared by the polynomials that view it: one polynomial, the halves of one ciphertext
+// ([half][limb][N], the layout the C-ABI takes), or a whole batch of ciphertexts an operation wrote in one call.
+// Released blocks go to a per-context pool and are handed out again for the same size: hipMalloc / hipFree cost far more than
+// the evaluator calls they would bracket (hipFree also waits for the device).  Reuse needs no synchronisation: every use of a
+// block, old or new, is enqueued on the context's one stream.  fHE::Context empties its pool when it is destroyed.
+struct block_pool {
+  std::unordered_map<fhe_hip_ctx *, std::unordered_map<size_t, std::vector<params::value_type *>>> free_;
+  std::unordered_map<fhe_hip_ctx *, size_t> held_words_;
+  static constexpr size_t kMaxHeldWords = (size_t)4 << 30;  // 32 GiB of idle blocks per context at most
+  static block_pool &get() { static block_pool p; return p; }
+  params::value_type *take(fhe_hip_ctx *c, size_t w) {
+    auto &v = free_[c][w];
+    if (v.empty()) return nullptr;
+    params::value_type *p = v.back();
+    v.pop_back(); held_words_[c] -= w;
+    return p;
+  }
+  void give(fhe_hip_ctx *c, size_t w, params::value_type *p) {
+    if (!free_.count(c)) return;  // the context is gone (a polynomial outlived its fHE::Context): nothing to free the block with
+    if (held_words_[c] + w > kMaxHeldWords) { fhe_hip_mem_free(c, p); return; }
+    free_[c][w].push_back(p); held_words_[c] += w;
+  }
+  void open(fhe_hip_ctx *c) { free_[c]; held_words_[c] = 0; }
+  void drain(fhe_hip_ctx *c) {  // before the context is destroyed
+    auto it = free_.find(c);
+    if (it == free_.end()) return;
+    for (auto &kv : it->second) for (auto *p : kv.second) fhe_hip_mem_free(c, p);
+    free_.erase(it); held_words_.erase(c);
+  }
+};
+struct dev_block {
+  fhe_hip_ctx *ctx; params::value_type *p = nullptr; size_t words;
+  dev_block(fhe_hip_ctx *c, size_t w) : ctx(c), words(w) {
+    p = block_pool::get().take(c, w);
+    if (!p) check(fhe_hip_mem_alloc(c, &p, w), "device allocation");
+  }
+  dev_block(dev_block const &) = delete;
+  dev_block &operator=(dev_block const &) = delete;
+  ~dev_block() { if (p) block_pool::get().give(ctx, words, p); }
+};
+using dev_block_ptr = std::shared_ptr<dev_block>;
+
+// limb-major polynomial [nmoduli][degree]; limb k lives under the global modulus index k.
+// Storage: a host copy and a device copy with lazy synchronisation (the "host mirror of device buffers" of SURVEY 8(a)
+// row a18).  Whoever touches the polynomial through the yell API (ptr_at / cptr_at / the host loops) gets a current host
+// copy, faulted back from the GPU when the device copy is the newer one; the device-side users (the transforms here, the
+// Evaluator / Encryptor / Decryptor of the host mirror) read and write the device copy through dev() / cdev() / adopt(), so
+// a chain of evaluator calls never moves a ciphertext over PCIe.
 class poly {
   using T = params::value_type;
-  std::vector<T> data_;
+  mutable std::vector<T> data_;       // host copy (sized lazily while the device copy is the current one)
+  mutable bool host_ok_ = true;       // host copy is current
+  mutable dev_block_ptr blk_;         // device copy: blk_->p + off_, nmoduli_ * degree words
+  mutable size_t off_ = 0;
+  mutable bool dev_ok_ = false;       // device copy is current
   size_t nmoduli_ = 0;
 
+  size_t words() const { return nmoduli_ * degree(); }
+  void need_host() const {
+    if (host_ok_) return;
+    data_.resize(words());
+    if (words()) check(fhe_hip_mem_copy(blk_->ctx, data_.data(), blk_->p + off_, words() * sizeof(T), FHE_HIP_COPY_D2H), "device -> host");
+    host_ok_ = true;
+  }
+  void need_dev() const {
+    if (dev_ok_) return;
+    if (!blk_ || blk_->words < off_ + words() || blk_->ctx != runtime::get().ctx) {
+      blk_ = std::make_shared<dev_block>(runtime::get().ctx, words());
+      off_ = 0;
+    }  // (a view keeps its own region of a shared block: views of one block never overlap, see adopt / relocate)
+    if (words()) check(fhe_hip_mem_copy(blk_->ctx, blk_->p + off_, data_.data(), words() * sizeof(T), FHE_HIP_COPY_H2D), "host -> device");
+    dev_ok_ = true;
+  }
+  void host_write() { need_host(); dev_ok_ = false; }   // before any host-side modification
+
   void set_small(const std::vector<int> &v) {
+    host_write();
     const size_t N = degree();
     for (size_t cm = 0; cm < nmoduli_; ++cm) {
       const T p = params::P[cm];
@@ -158,15 +228,44 @@ class poly {
 
   explicit poly(size_t nmoduli = 0) : data_(nmoduli * degree(), 0), nmoduli_(nmoduli), logn(runtime::get().logn) {}
   template <class Dist> poly(size_t nmoduli, Dist const &dist) : poly(nmoduli) { set(dist); }
+  // value semantics; a copy takes whichever side is current (device -> device when the host copy is stale)
+  poly(poly const &o) : host_ok_(o.host_ok_), nmoduli_(o.nmoduli_), logn(o.logn) {
+    if (o.host_ok_) data_ = o.data_;
+    else {
+      blk_ = std::make_shared<dev_block>(o.blk_->ctx, words());
+      if (words()) check(fhe_hip_mem_copy(blk_->ctx, blk_->p, o.blk_->p + o.off_, words() * sizeof(T), FHE_HIP_COPY_D2D), "device copy");
+      dev_ok_ = true;
+    }
+  }
+  poly(poly &&) = default;
+  poly &operator=(poly const &o) { if (this != &o) { poly t(o); *this = std::move(t); } return *this; }
+  poly &operator=(poly &&) = default;
 
   size_t moduli_count() const { return nmoduli_; }
-  T *ptr_at(size_t cm) { return data_.data() + cm * degree(); }
-  const T *cptr_at(size_t cm) const { return data_.data() + cm * degree(); }
+  T *ptr_at(size_t cm) { host_write(); return data_.data() + cm * degree(); }
+  const T *cptr_at(size_t cm) const { need_host(); return data_.data() + cm * degree(); }
   const T *cptr_end(size_t cm) const { return cptr_at(cm) + degree(); }
-  void resize_moduli_count(size_t n) { data_.resize(n * degree(), 0); nmoduli_ = n; }
-  void clear() { std::fill(data_.begin(), data_.end(), 0); }
+  void resize_moduli_count(size_t n) { need_host(); data_.resize(n * degree(), 0); nmoduli_ = n; dev_ok_ = false; blk_.reset(); off_ = 0; }
+  void clear() { data_.assign(words(), 0); host_ok_ = true; dev_ok_ = false; }
+
+  // ---- device side ------------------------------------------------------------------------------------------------
+  bool on_device() const { return dev_ok_; }                       // the device copy is current
+  bool host_current() const { return host_ok_; }
+  const T *cdev() const { need_dev(); return blk_->p + off_; }     // current device copy, read-only
+  T *dev() { need_dev(); host_ok_ = false; return blk_->p + off_; }  // ... to be overwritten / updated by a device call
+  dev_block_ptr const &block() const { return blk_; }
+  size_t block_offset() const { return off_; }
+  // become a view of `n` limbs at word offset `off` of a block a device call has just written (or is about to write)
+  void adopt(dev_block_ptr const &b, size_t off, size_t n) { blk_ = b; off_ = off; nmoduli_ = n; dev_ok_ = true; host_ok_ = false; }
+  // same content, device copy relocated to (b, off): used to make the halves of a ciphertext contiguous
+  void relocate(dev_block_ptr const &b, size_t off) const {
+    if (dev_ok_) { if (words()) check(fhe_hip_mem_copy(b->ctx, b->p + off, blk_->p + off_, words() * sizeof(T), FHE_HIP_COPY_D2D), "device copy"); }
+    else if (words()) check(fhe_hip_mem_copy(b->ctx, b->p + off, data_.data(), words() * sizeof(T), FHE_HIP_COPY_H2D), "host -> device");
+    blk_ = b; off_ = off; dev_ok_ = true;
+  }
 
   void set(uniform const &) {
+    host_write();
     const size_t N = degree();
     for (size_t cm = 0; cm < nmoduli_; ++cm) { const T p = params::P[cm]; for (size_t d = 0; d < N; ++d) data_[cm * N + d] = prng::global().next() % p; }
   }
@@ -187,28 +286,37 @@ class poly {
     set_small(v);
   }
 
-  // yell::poly::forward/backward: every limb, on the GPU through the C-ABI (host buffers are staged by the library)
+  // yell::poly::forward/backward: every limb, on the GPU through the C-ABI, on the device copy (no PCIe round trip
+  // between consecutive device-side operations)
   void forward() { transform(false); }
   void forward_lazy() { transform(false); }  // yell's lazy variant skips the final correction; canonical here
   void backward() { transform(true); }
 
   poly &operator+=(poly const &o) {
     assert(o.nmoduli_ == nmoduli_);
+    if (dev_ok_ && o.dev_ok_ && !host_ok_) {  // both live on the GPU: add there
+      check(fhe_hip_add(runtime::get().ctx, dev(), o.cdev(), (uint32_t)nmoduli_, 1, FHE_HIP_MEM_DEVICE), "add");
+      return *this;
+    }
+    host_write(); o.need_host();
     ops::addmod add; const size_t N = degree();
     for (size_t cm = 0; cm < nmoduli_; ++cm) for (size_t d = 0; d < N; ++d) add.compute(data_[cm * N + d], o.data_[cm * N + d], cm);
     return *this;
   }
   poly &operator*=(poly const &o) {
     assert(o.nmoduli_ >= nmoduli_);
+    host_write(); o.need_host();
     ops::mulmod mul; const size_t N = degree();
     for (size_t cm = 0; cm < nmoduli_; ++cm) for (size_t d = 0; d < N; ++d) mul.compute(data_[cm * N + d], o.data_[cm * N + d], cm);
     return *this;
   }
   void add_product_of(poly const &a, poly const &b) {  // *this += a * b (pointwise)
+    host_write();
     ops::muladd ma; const size_t N = degree();
     for (size_t cm = 0; cm < nmoduli_; ++cm) for (size_t d = 0; d < N; ++d) data_[cm * N + d] = ma(data_[cm * N + d], a.cptr_at(cm)[d], b.cptr_at(cm)[d], cm);
   }
   void negate() {
+    host_write();
     const size_t N = degree();
     for (size_t cm = 0; cm < nmoduli_; ++cm) { const T p = params::P[cm]; for (size_t d = 0; d < N; ++d) { T &x = data_[cm * N + d]; x = x ? p - x % p : 0; } }
   }
@@ -219,8 +327,9 @@ class poly {
     std::vector<uint32_t> idx(nmoduli_);
     std::iota(idx.begin(), idx.end(), 0u);
     auto &rt = runtime::get();
-    check(inverse ? fhe_hip_ntt_backward(rt.ctx, data_.data(), idx.data(), nmoduli_, FHE_HIP_MEM_HOST)
-                  : fhe_hip_ntt_forward(rt.ctx, data_.data(), idx.data(), nmoduli_, FHE_HIP_MEM_HOST), "ntt");
+    T *d = dev();
+    check(inverse ? fhe_hip_ntt_backward(rt.ctx, d, idx.data(), nmoduli_, FHE_HIP_MEM_DEVICE)
+                  : fhe_hip_ntt_forward(rt.ctx, d, idx.data(), nmoduli_, FHE_HIP_MEM_DEVICE), "ntt");
   }
 };
 

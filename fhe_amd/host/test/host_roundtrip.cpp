@@ -25,7 +25,55 @@ static void dump(FILE *f, const char *name, fHE::context::poly_t const &p) {
   std::fwrite(p.cptr_at(0), 8, n * fHE::context::degree, f);
 }
 
+// host_roundtrip bench <logN> <L> <K> <batch> <reps>: multiply_and_relin per second THROUGH THE C++ API with the ciphertexts
+// resident on the GPU (fHE::Cipher keeps its limbs in device memory; yell/poly.hpp), batched overload and one-at-a-time.
+// Each repetition starts from fresh Li-limb copies (device-to-device, outside the timed region); the timed region is the
+// Evaluator call(s) up to the completion of the device work.
+static int bench_mode(int argc, char **argv) {
+  const uint32_t logN = argc > 2 ? std::atoi(argv[2]) : 16, L = argc > 3 ? std::atoi(argv[3]) : 30, K = argc > 4 ? std::atoi(argv[4]) : 1;
+  const size_t B = argc > 5 ? std::atoi(argv[5]) : 16, reps = argc > 6 ? std::atoi(argv[6]) : 5;
+  fHE::Context context(logN, L, K, 0);
+  fHE::SK sk;
+  fHE::PK pk(sk);
+  fHE::MultKey mkey(sk);
+  fHE::Encryptor encryptor;
+  fHE::Evaluator evaluator;
+  fHE::context::poly_t msg(L);
+  fHE::Cipher c0, c1;
+  if (!encryptor.encrypt(&c0, msg, pk) || !encryptor.encrypt(&c1, msg, pk)) return 40;
+  std::vector<fHE::Cipher> src0(B, c0), src1(B, c1);
+  std::vector<fHE::Cipher const *> rhs;
+  for (auto &c : src1) rhs.push_back(&c);
+  { fHE::Cipher warm(c0); if (!evaluator.multiply_and_relin(&warm, c1, mkey)) return 41; }  // uploads the key
+  auto timed = [&](bool batched) {
+    double total = 0;
+    for (size_t r = 0; r < reps + 1; ++r) {
+      std::vector<fHE::Cipher> work(src0);
+      std::vector<fHE::Cipher *> lhs;
+      for (auto &c : work) lhs.push_back(&c);
+      fhe_hip_sync(context.handle());
+      const auto t0 = std::chrono::steady_clock::now();
+      bool ok = true;
+      if (batched) ok = evaluator.multiply_and_relin(lhs, rhs, mkey);
+      else for (size_t b = 0; b < B && ok; ++b) ok = evaluator.multiply_and_relin(lhs[b], *rhs[b], mkey);
+      fhe_hip_sync(context.handle());
+      const auto t1 = std::chrono::steady_clock::now();
+      if (!ok) return -1.0;
+      if (r) total += std::chrono::duration<double>(t1 - t0).count();  // repetition 0 is the warm-up (workspaces, gather)
+    }
+    return (double)(B * reps) / total;
+  };
+  const double rb = timed(true), r1 = timed(false);
+  if (rb < 0 || r1 < 0) return 42;
+  std::printf("{\"api\": \"fHE::Evaluator::multiply_and_relin (C++ host mirror, ciphertexts device-resident)\", \"logN\": %u, \"Li\": %u, \"batch\": %zu, "
+              "\"reps\": %zu, \"batched_ops_per_s\": %.1f, \"one_at_a_time_ops_per_s\": %.1f}\n", logN, L, B, reps, rb, r1);
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 1 && std::string(argv[1]) == "bench") {
+    try { return bench_mode(argc, argv); } catch (std::exception const &e) { std::fprintf(stderr, "exception: %s\n", e.what()); return 1; }
+  }
   const uint32_t logN = argc > 1 ? std::atoi(argv[1]) : 13, L = argc > 2 ? std::atoi(argv[2]) : 4, K = argc > 3 ? std::atoi(argv[3]) : 4;
   const char *path = argc > 4 ? argv[4] : "host_roundtrip.bin";
   try {

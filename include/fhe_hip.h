@@ -80,6 +80,22 @@ int fhe_hip_rescale(fhe_hip_ctx *ctx, uint64_t *rop, const uint64_t *op, uint32_
  * approximated_mod_down before its NTT, :220-223).  approx_convert_to_special_basis (:276-295) is the special-limb part
  * of fhe_hip_mod_up. */
 int fhe_hip_conv_to_normal(fhe_hip_ctx *ctx, uint64_t *rop, const uint64_t *sp, uint32_t L0, size_t batch, int mem_kind);
+/* BaseConverter::approx_convert_to_special_basis (include/fHE/base_converter.hpp:30-32, src/base_converter.cpp:276-295) for ONE
+ * special prime: op = [batch][Li][N] power basis -> rop = [batch][N], the residues under P[L + sp_index] (uncorrected, as
+ * fhe_hip_mod_up computes for all K special primes at once).  Li <= 1 -> FHE_HIP_ERR_RANGE (:284-285). */
+int fhe_hip_conv_to_special(fhe_hip_ctx *ctx, uint64_t *rop, const uint64_t *op, uint32_t Li, uint32_t sp_index, size_t batch, int mem_kind);
+
+/* Device memory for host-language callers that keep polynomials on the GPU between calls: the device side of the storage
+ * behind yell::poly / fHE::Cipher (reference include/fHE/cipher.hpp:5-50; the reference, a CPU library,
+ * has host vectors only).  Blocks are plain device memory of the context's GPU, usable as FHE_HIP_MEM_DEVICE operands.
+ * fhe_hip_mem_copy is ordered on the context's stream; it returns once a host buffer involved is the caller's again
+ * (host <-> device: after completion; device -> device: enqueued).  fhe_hip_mem_free waits for the context's stream first. */
+#define FHE_HIP_COPY_H2D 1
+#define FHE_HIP_COPY_D2H 2
+#define FHE_HIP_COPY_D2D 3
+int fhe_hip_mem_alloc(fhe_hip_ctx *ctx, uint64_t **dptr, size_t words);
+int fhe_hip_mem_free(fhe_hip_ctx *ctx, uint64_t *dptr);
+int fhe_hip_mem_copy(fhe_hip_ctx *ctx, void *dst, const void *src, size_t bytes, int direction);
 
 /* MultKey (include/fHE/mult_key.hpp:5-38): beta/alpha = [L][L][N] (key j, limb i), NTT basis.
  * RotKey (include/fHE/rot_key.hpp:9-39): beta/alpha = [L+K][N], NTT basis, selected later by galois.

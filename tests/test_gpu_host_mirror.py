@@ -38,7 +38,9 @@ def _load_dump(path, N):
 @pytest.mark.parametrize("logN,L,K", [(13, 4, 4), (12, 3, 2), (16, 4, 4)])
 def test_config1_roundtrip_through_cpp_api(tmp_path, logN, L, K):
     path = str(tmp_path / "dump.bin")
-    r = subprocess.run([BIN, str(logN), str(L), str(K), path], capture_output=True, text=True, timeout=300)
+    # FHE_HOST_SEED: the host samplers are seeded from OS entropy by default (yell/poly.hpp); a fixed seed makes a failure reproducible
+    r = subprocess.run([BIN, str(logN), str(L), str(K), path], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, FHE_HOST_SEED=str(1000 + logN)))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "host_roundtrip OK" in r.stdout
     # two Evaluators on one context alternating two MultKeys, and a RotKey rebuilt at a destroyed key's address
@@ -143,3 +145,30 @@ def test_config1_roundtrip_through_cpp_api(tmp_path, logN, L, K):
         rb_, ra_ = o.add(rb_, tb), o.add(ra_, ta)
     rb_ = o.ntt_forward(rb_, range(L)); ra_ = o.ntt_forward(ra_, range(L))
     assert np.array_equal(d["rep_bx"][0], rb_) and np.array_equal(d["rep_ax"][0], ra_)
+
+
+@pytest.mark.gpu
+def test_host_samplers_are_seeded_from_entropy_unless_told_otherwise(tmp_path):
+    """Two runs without FHE_HOST_SEED draw different secret keys; two runs with the same seed draw the same one."""
+    def secret(env, name):
+        path = str(tmp_path / name)
+        r = subprocess.run([BIN, "12", "3", "2", path], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return _load_dump(path, 1 << 12)[1]["sx"][0]
+    base = {k: v for k, v in os.environ.items() if k != "FHE_HOST_SEED"}
+    assert not np.array_equal(secret(base, "a.bin"), secret(base, "b.bin"))
+    seeded = dict(base, FHE_HOST_SEED="7")
+    assert np.array_equal(secret(seeded, "c.bin"), secret(seeded, "d.bin"))
+
+
+@pytest.mark.gpu
+def test_cpp_api_keeps_ciphertexts_on_the_device(tmp_path):
+    """`host_roundtrip bench`: multiply_and_relin through fHE::Evaluator with device-resident fHE::Cipher objects, batched overload
+    and one call per ciphertext; here at a small shape (the C3 figure is measured by tools/gpu_r3_host_api.sh and recorded in
+    BASELINE.md).  The batched overload must not be slower than one call per ciphertext."""
+    import json
+    r = subprocess.run([BIN, "bench", "13", "6", "1", "8", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["batch"] == 8 and line["batched_ops_per_s"] > 0 and line["one_at_a_time_ops_per_s"] > 0
+    assert line["batched_ops_per_s"] >= 0.9 * line["one_at_a_time_ops_per_s"]
