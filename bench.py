@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_SIMD = 256 * 4       # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs
+VALU_CHEAP_CYCLES = 2  # plain 32-bit VOP1/VOP2 (measured 2.3-2.7 per wave64: profiles/r02_first/instrate2.txt)
 VALU_ISSUE_CYCLES = 4  # cycles one wave64 multiply-add / 64-bit / carry instruction holds a SIMD's issue port
 
 WORKLOADS = {
@@ -263,12 +264,27 @@ def launch_ranks(n):
     return next((rc for rc in rcs if rc), 0)
 
 
+KERNEL_SOURCES = ("modarith.h", "ntt_kernels.h", "pointwise_kernels.h", "fhe_hip.hip")
+
+
+def kernel_source_sha16():
+    """Identity of the kernel sources of the library being timed (the committed counter files carry the hash of the sources
+    they were measured on: tools/stamp_profiles.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "fhe_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def read_profile_json(kind, workload):
+    """profiles/<kind>_<workload>.json, or None when absent or measured on other kernel sources than the ones being timed."""
     path = os.path.join(ROOT, "profiles", "%s_%s.json" % (kind, workload))
     try:
-        return json.load(open(path))
+        j = json.load(open(path))
     except Exception:
         return None
+    return j if j.get("kernel_source_sha16") == kernel_source_sha16() else None
 
 
 class Setup:
@@ -446,29 +462,46 @@ class Setup:
         default_batch = self.B == WORKLOADS[w][4] and self.primes_kind == "sp"  # the committed counter passes ran this shape on the SP table
         tj = read_profile_json("traffic", w) if default_batch else None
         traffic = tj.get("hbm_bytes_per_launch") if tj else None
+        bytes_key = "min_bytes_of_this_design_per_launch" if w in MULT else "alg_bytes_per_launch"
         roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "alg_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches": launches}
+                bytes_key: alg, "avg_launch_ms": avg_ms, "launches": launches}
+        if w in MULT:
+            roof["bytes_note"] = ("bytes this launch of the two-kernel relinearisation has to move once: 2*Li^2 key limbs, per ciphertext the Li^2 "
+                                  "column-pass limbs (an intermediate of this design, not algorithmic bytes of the operation), 2*Li addends, 2*Li results")
+        if default_batch and not tj:
+            roof["traffic_note"] = "null: profiles/traffic_%s.json is absent or was measured on other kernel sources (kernel_source_sha16)" % w
         if traffic:
             roof["traffic_frac"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if tj and tj.get("hbm_bytes_per_step"):
+            # what the counters saw over ALL kernels of a step against the operation's algorithmic bytes (keys amortised
+            # over the batch): the traffic the design adds (column-pass output written and re-read, intermediate ciphertexts)
+            alg_step = B * 8 * N * (6 * Li - 2 + 2 * Li * Li / B) if w in MULT else self.per_step_units * algorithmic_bytes(w, N, Li, K)
+            roof["traffic_per_step"] = tj["hbm_bytes_per_step"]
+            roof["alg_bytes_per_step_key_amortised" if w in MULT else "alg_bytes_per_step"] = alg_step
+            roof["traffic_over_algorithmic"] = tj["hbm_bytes_per_step"] / alg_step
         if per_op != alg:
             roof["per_op_keys"] = {"alg_bytes_per_launch": per_op, "achieved": per_op / (avg_ms * 1e-3) / 1e9,
                                    "frac": per_op / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "note": "SURVEY 8(d) per-op convention: the 2*Li^2 key limbs charged to every ciphertext of the batch; "
                                            "the counters show they are fetched once per launch, so this is not HBM traffic"}
-        # VALU issue: committed PMC pass (profiles/valu_<workload>.json: SQ_INSTS_VALU and GRBM_GUI_ACTIVE of this kernel)
+        # VALU issue, entirely from ONE committed PMC pass of the dominant kernel (profiles/valu_<workload>.json: SQ_INSTS_VALU and
+        # GRBM_GUI_ACTIVE of the same dispatches; no figure of this run enters): issue cycles the instruction stream needs at the
+        # least each class can cost (2 for plain 32-bit VOP1/VOP2, 4 for everything else: profiles/r02_first/instrate2.txt measures
+        # 2.3-2.7 and 4.1-4.7) over the SIMD cycles the launch had.  A lower bound on busy cycles over available cycles: <= 1.
         valu = None
         vj = read_profile_json("valu", w) if default_batch else None
-        if vj and vj.get("insts_valu_per_launch") and vj.get("gui_active_per_xcd_per_launch") and vj.get("launch_ms_in_pmc_pass"):
-            slots = vj["insts_valu_per_launch"] * VALU_ISSUE_CYCLES / N_SIMD    # issue cycles per SIMD the launch needs
-            sclk_mhz = vj["gui_active_per_xcd_per_launch"] / (vj["launch_ms_in_pmc_pass"] * 1e3)
-            live = slots / (sclk_mhz * 1e3 * avg_ms)
+        if vj and vj.get("insts_valu_per_launch") and vj.get("gui_active_per_xcd_per_launch") and vj.get("cheap_share") is not None:
+            cs = vj["cheap_share"]
+            need = vj["insts_valu_per_launch"] * (VALU_ISSUE_CYCLES * (1 - cs) + VALU_CHEAP_CYCLES * cs)
+            have = N_SIMD * vj["gui_active_per_xcd_per_launch"]
             valu = {"bound": "valu-issue", "kernel": kname, "insts_valu_per_launch": vj["insts_valu_per_launch"],
-                    "issue_cycles_per_inst": VALU_ISSUE_CYCLES, "simds": N_SIMD, "sclk_mhz_pmc_pass": sclk_mhz,
-                    "frac_pmc_pass": slots / vj["gui_active_per_xcd_per_launch"], "frac": live,
-                    "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x sclk x launch time); sclk = GRBM_GUI_ACTIVE per XCD / launch time "
-                            "in the committed PMC pass, launch time = this run's avg_launch_ms", "source": vj.get("source")}
-            if live > roof["frac"]:
+                    "cheap_share": cs, "issue_cycles": {"plain_32bit_vop": VALU_CHEAP_CYCLES, "other": VALU_ISSUE_CYCLES}, "simds": N_SIMD,
+                    "simd_cycles_available": have, "issue_cycles_needed": need, "frac": need / have,
+                    "sclk_mhz_pmc_pass": vj["gui_active_per_xcd_per_launch"] / (vj["launch_ms_in_pmc_pass"] * 1e3) if vj.get("launch_ms_in_pmc_pass") else None,
+                    "note": "SQ_INSTS_VALU x class-weighted minimum issue cycles / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD), all from the committed "
+                            "PMC pass of this kernel on these kernel sources", "source": vj.get("source")}
+            if valu["frac"] > roof["frac"]:
                 roof["bound"] = "valu-issue (see roofline_valu): the kernel sits nearer its VALU issue limit than the HBM roofline"
         return roof, valu
 

@@ -323,6 +323,14 @@ def test_mod_up_mod_down_rescale(logN, L, K, Li, sp):
     up = host(g.mod_up(torch.zeros((2, Li + K, o.N), dtype=torch.int64, device="cuda"), dev(x), Li, batch=2))
     for k in range(K):
         assert np.array_equal(up[1, Li + k], o.approx_convert_to_special_basis(x[1], k))
+        one = g.conv_to_special(torch.zeros((2, o.N), dtype=torch.int64, device="cuda"), dev(x), Li, k, batch=2)  # the single-target entry point
+        assert np.array_equal(host(one), up[:, Li + k])
+    hone = np.zeros((2, o.N), np.uint64)
+    g.conv_to_special(hone, x.copy(), Li, K - 1, batch=2)  # host buffers
+    assert np.array_equal(hone, up[:, Li + K - 1])
+    with pytest.raises(fhe_amd.FheHipError) as ei:
+        g.conv_to_special(torch.zeros((1, o.N), dtype=torch.int64, device="cuda"), dev(x[:1]), Li, K)
+    assert ei.value.code == -2
     sp_part = np.ascontiguousarray(y[:, Li:])
     for L0 in sorted({1, Li, L}):
         rop = torch.zeros((2, L0, o.N), dtype=torch.int64, device="cuda")

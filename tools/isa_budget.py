@@ -7,12 +7,20 @@ usage: tools/isa_budget.py [out.txt]"""
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 asm = os.path.join(tempfile.gettempdir(), "fhe_budget.s")
-subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "--rocm-path=/opt/rocm", "-O3", "-std=c++17", "--offload-arch=gfx950", "-x", "hip", "-S",
-                       "--cuda-device-only", "-w", "-o", asm, os.path.join(ROOT, "fhe_amd", "csrc", "fhe_hip.hip")])
-text = open(asm).read()
+text = None
+
+
+def compile_asm():
+    global text
+    if text is None:
+        subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "--rocm-path=/opt/rocm", "-O3", "-std=c++17", "--offload-arch=gfx950", "-x", "hip", "-S",
+                               "--cuda-device-only", "-w", "-o", asm, os.path.join(ROOT, "fhe_amd", "csrc", "fhe_hip.hip")])
+        text = open(asm).read()
+    return text
 
 
 def body_of(sym):
+    compile_asm()
     m = re.search(r'^(%s):[^\n]*\n(.*?)^\.Lfunc_end' % re.escape(sym), text, re.S | re.M)
     return [l.strip() for l in m.group(2).split('\n')]
 
@@ -47,41 +55,56 @@ def classes(ops):
     return valu, mad, cheap, ops.get('s_nop', 0), sum(v for k, v in ops.items() if k.startswith('ds_')), sum(v for k, v in ops.items() if k.startswith('global_'))
 
 
-K = [
-    # symbol, label, butterflies per thread, key MACs / scaling multiplies per thread, canonical outputs per thread, loop?
-    ("_Z15ntt_cols_kernelILb1ELb0ELi8EEv7NttArgs", "ntt_cols_kernel<SP,fwd,8>: stand-alone and relinearisation column pass", 64, 0, 0, False),
-    ("_Z20ntt_rows8_fwd_kernelILb1ELi0EEv7NttArgs", "ntt_rows8_fwd_kernel<SP,0>: stand-alone forward row pass", 32, 0, 8, False),
-    ("_Z20ntt_rows8_inv_kernelILb1ELb0ELb0EEv7NttArgs", "ntt_rows8_inv_kernel<SP>: inverse row pass", 32, 0, 0, False),
-    ("_Z15ntt_cols_kernelILb1ELb1ELi8EEv7NttArgs", "ntt_cols_kernel<SP,inv,8>: inverse column pass + N^-1 scaling", 64, 16, 16, False),
-    ("_Z23relin_rows8p_mac_kernelILb1EEv9RelinArgs", "relin_rows8p_mac_kernel<SP>: one digit of the j-loop (row pass + 16 key MACs)", 32, 16, 0, True),
-]
-# the generic-prime instantiations (any odd p < 2^62: what a drop-in caller's own table runs): ideal = 23 per butterfly
-# (16-instruction word-serial Montgomery, modarith.h:mont_generic, + 7), 21 per key MAC / scaling multiply
-KG = [(sym.replace("ILb1E", "ILb0E", 1), label.replace("<SP", "<generic"), bf, macs, canon, loop) for sym, label, bf, macs, canon, loop in K]
-out = ["static VALU budget per thread, gfx950 (-O3); ideal = 18 per butterfly + 16 per key MAC / scaling multiply + 8 per canonical output",
-       "%-82s %5s %5s %6s %6s %8s %7s %5s %6s %6s" % ("kernel", "bfly", "MACs", "VALU", "ideal", "VALU/bf", "excess", "mads", "cheap", "s_nop")]
-for sym, label, bf, macs, canon, loop in K:
+def cheap_share(sym, loop=False):
+    """share of the plain 32-bit VOP1/VOP2 class among a kernel's VALU instructions (loop: of its main loop's)"""
     lines = body_of(sym)
     if loop:
         a, b = main_loop(lines)
         lines = lines[a:b + 1]
     valu, mad, cheap, nops, lds, vmem = classes(count(lines))
-    ideal = 18 * bf + 16 * macs + 8 * canon
-    out.append("%-82s %5d %5d %6d %6d %8.2f %6.1f%% %5d %6d %6d   (LDS %d, vector-memory %d)" %
-               (label, bf, macs, valu, ideal, (valu - 16 * macs - 8 * canon) / bf, 100.0 * (valu - ideal) / ideal, mad, cheap, nops, lds, vmem))
-out.append("generic primes: ideal = 23 per butterfly + 21 per key MAC / scaling multiply + 8 per canonical output")
-for sym, label, bf, macs, canon, loop in KG:
-    lines = body_of(sym)
-    if loop:
-        a, b = main_loop(lines)
-        lines = lines[a:b + 1]
-    valu, mad, cheap, nops, lds, vmem = classes(count(lines))
-    ideal = 23 * bf + 21 * macs + 8 * canon
-    out.append("%-82s %5d %5d %6d %6d %8.2f %6.1f%% %5d %6d %6d   (LDS %d, vector-memory %d)" %
-               (label, bf, macs, valu, ideal, (valu - 21 * macs - 8 * canon) / bf, 100.0 * (valu - ideal) / ideal, mad, cheap, nops, lds, vmem))
-out.append("VALU/bf = (VALU - 16*MACs - 8*canonical outputs) / butterflies; cheap = plain 32-bit VOP1/VOP2 (v_mov/not/add/sub/and/or/xor): the only class that")
-out.append("issues faster than a multiply-add, and only back to back with another of its kind (instrate2.txt: mad + add32 = 8.8 cycles, mad + 2 add32 = 10.4).")
-res = "\n".join(out)
-print(res)
-if len(sys.argv) > 1:
-    open(sys.argv[1], "w").write(res + "\n")
+    return cheap / valu
+
+
+def report(argv):
+    K = [
+        # symbol, label, butterflies per thread, key MACs / scaling multiplies per thread, canonical outputs per thread, loop?
+        ("_Z15ntt_cols_kernelILb1ELb0ELi8EEv7NttArgs", "ntt_cols_kernel<SP,fwd,8>: stand-alone and relinearisation column pass", 64, 0, 0, False),
+        ("_Z20ntt_rows8_fwd_kernelILb1ELi0EEv7NttArgs", "ntt_rows8_fwd_kernel<SP,0>: stand-alone forward row pass", 32, 0, 8, False),
+        ("_Z20ntt_rows8_inv_kernelILb1ELb0ELb0EEv7NttArgs", "ntt_rows8_inv_kernel<SP>: inverse row pass", 32, 0, 0, False),
+        ("_Z15ntt_cols_kernelILb1ELb1ELi8EEv7NttArgs", "ntt_cols_kernel<SP,inv,8>: inverse column pass + N^-1 scaling", 64, 16, 16, False),
+        ("_Z23relin_rows8p_mac_kernelILb1EEv9RelinArgs", "relin_rows8p_mac_kernel<SP>: one digit of the j-loop (row pass + 16 key MACs)", 32, 16, 0, True),
+    ]
+    # the generic-prime instantiations (any odd p < 2^62: what a drop-in caller's own table runs): ideal = 23 per butterfly
+    # (16-instruction word-serial Montgomery, modarith.h:mont_generic, + 7), 21 per key MAC / scaling multiply
+    KG = [(sym.replace("ILb1E", "ILb0E", 1), label.replace("<SP", "<generic"), bf, macs, canon, loop) for sym, label, bf, macs, canon, loop in K]
+    out = ["static VALU budget per thread, gfx950 (-O3); ideal = 18 per butterfly + 16 per key MAC / scaling multiply + 8 per canonical output",
+           "%-82s %5s %5s %6s %6s %8s %7s %5s %6s %6s" % ("kernel", "bfly", "MACs", "VALU", "ideal", "VALU/bf", "excess", "mads", "cheap", "s_nop")]
+    for sym, label, bf, macs, canon, loop in K:
+        lines = body_of(sym)
+        if loop:
+            a, b = main_loop(lines)
+            lines = lines[a:b + 1]
+        valu, mad, cheap, nops, lds, vmem = classes(count(lines))
+        ideal = 18 * bf + 16 * macs + 8 * canon
+        out.append("%-82s %5d %5d %6d %6d %8.2f %6.1f%% %5d %6d %6d   (LDS %d, vector-memory %d)" %
+                   (label, bf, macs, valu, ideal, (valu - 16 * macs - 8 * canon) / bf, 100.0 * (valu - ideal) / ideal, mad, cheap, nops, lds, vmem))
+    out.append("generic primes: ideal = 23 per butterfly + 21 per key MAC / scaling multiply + 8 per canonical output")
+    for sym, label, bf, macs, canon, loop in KG:
+        lines = body_of(sym)
+        if loop:
+            a, b = main_loop(lines)
+            lines = lines[a:b + 1]
+        valu, mad, cheap, nops, lds, vmem = classes(count(lines))
+        ideal = 23 * bf + 21 * macs + 8 * canon
+        out.append("%-82s %5d %5d %6d %6d %8.2f %6.1f%% %5d %6d %6d   (LDS %d, vector-memory %d)" %
+                   (label, bf, macs, valu, ideal, (valu - 21 * macs - 8 * canon) / bf, 100.0 * (valu - ideal) / ideal, mad, cheap, nops, lds, vmem))
+    out.append("VALU/bf = (VALU - 16*MACs - 8*canonical outputs) / butterflies; cheap = plain 32-bit VOP1/VOP2 (v_mov/not/add/sub/and/or/xor): the only class that")
+    out.append("issues faster than a multiply-add, and only back to back with another of its kind (instrate2.txt: mad + add32 = 8.8 cycles, mad + 2 add32 = 10.4).")
+    res = "\n".join(out)
+    print(res)
+    if len(argv) > 1:
+        open(argv[1], "w").write(res + "\n")
+
+
+if __name__ == "__main__":
+    report(sys.argv)

@@ -13,4 +13,4 @@ for name, ctrs in sorted(agg.items()):
     print(name)
     for c, vals in sorted(ctrs.items()):
         vals = sorted(vals)
-        print("   %-24s n=%-4d max=%.4g median=%.4g" % (c, len(vals), vals[-1], vals[len(vals) // 2]))
+        print("   %-24s n=%-4d max=%.4g median=%.4g sum=%.6g" % (c, len(vals), vals[-1], vals[len(vals) // 2], sum(vals)))
