@@ -165,4 +165,21 @@ def test_pipelined_batch_run_beats_the_synchronous_path():
     print("batch_run pipeline: sync %.1f ms, pipelined %.1f ms, %.2fx; %.0f op/s from pageable host memory" %
           (best["sync"] * 1e3, best["pipe"] * 1e3, ratio, batch / best["pipe"]))
     assert ratio >= 1.5, (best, ratio)
+    # the same call from pinned (page-locked) host buffers: same bits, and not slower than from pageable memory (measured
+    # round 2: 2 676 against 1 923 op/s; the copies no longer go through the runtime's staging buffers)
+    pin = lambda a: torch.from_numpy(a.view(np.int64)).pin_memory().numpy().view(np.uint64)  # noqa: E731
+    p0, p1 = pin(c0), pin(c1)
+    out_pin = torch.zeros((batch, 2, Li - 1, N), dtype=torch.int64).pin_memory().numpy().view(np.uint64)
+
+    def pinned():
+        hip.batch_run([g], hip.OP_MUL_RELIN_RESCALE, out_pin, p0, p1, Li=Li, batch=batch)
+    pinned()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        pinned()
+        ts.append(time.perf_counter() - t0)
+    assert np.array_equal(out_pin, out_s)
+    print("batch_run from pinned host memory: %.1f ms, %.0f op/s" % (min(ts) * 1e3, batch / min(ts)))
+    assert min(ts) <= 1.05 * best["pipe"], (min(ts), best)
     g.close()
