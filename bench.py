@@ -8,8 +8,9 @@ A "step" is one pass of the hot path over one batch of synthetic, HBM-resident i
   --workload c2  N=2^14, 8 limbs x 1024 polys forward+inverse NTT
   --workload c4  N=2^16, Li=K=30 rotation key switch
   --workload c5  N=2^15, Li=16 multiply+relin+rescale
-  --workload rotm | rotnn | dec | enc   the SURVEY 8(f) rows: MixedRotKey rotation, power-basis rotation, decrypt and encrypt
-                 inner loops (N=2^16, Li=30); their `roofline` is the whole pipeline against the op's algorithmic bytes
+  --workload rotm | rotnn | dec | enc | encode | decode   the SURVEY 8(f) rows: MixedRotKey rotation, power-basis rotation, decrypt
+                 and encrypt inner loops, the Encoder (N=2^16, Li=30); their `roofline` is the whole pipeline against the op's
+                 algorithmic bytes
 Before the W warmup steps the steps run untimed for --prewarm seconds (clock ramp).  The K timed steps
 run with the library's per-launch events OFF; the per-kernel durations (`kernel_ms`, `roofline`) come from a second, untimed
 pass of the same steps with the events on.  The default (c3) run also carries `ntt_n16`: 2048 forward limb-NTTs at N=2^16,
@@ -54,8 +55,10 @@ WORKLOADS = {
     "rotnn": (16, 30, 30, 30, 16),  # rank 2: power-basis rotation (rotate_slots_non_ntt)
     "dec": (16, 30, 1, 30, 64),     # rank 3: decrypt inner loops
     "enc": (16, 30, 1, 30, 64),     # rank 3: encrypt inner loops
+    "encode": (16, 30, 1, 30, 64),  # rank 4: Encoder::encode on the device (slots -> Li-limb plaintext polynomial)
+    "decode": (16, 30, 1, 30, 64),  # rank 4: Encoder::decode on the device
 }
-GENERIC = ("rotm", "rotnn", "dec", "enc")
+GENERIC = ("rotm", "rotnn", "dec", "enc", "encode", "decode")
 MULT = ("c3", "c5")
 
 
@@ -129,6 +132,8 @@ def algorithmic_bytes(workload, N, Li, K):
         return 8 * N * (4 * Li + 2 * Li * (Li + 1))
     if workload == "dec":   # ct (2*Li) + sx (Li) in, Li out
         return 8 * N * 4 * Li
+    if workload in ("encode", "decode"):  # N/2 complex slots (16 B each) on one side, Li limbs on the other
+        return 8 * N + 8 * N * Li
     if workload == "enc":   # u, e0+m, e1 (3*Li) + pk (2*Li) in, 2*Li out
         return 8 * N * 7 * Li
     return 16 * N  # one limb-NTT
@@ -196,6 +201,9 @@ def cpu_baseline(workload, logN, L, K, Li, inputs, budget_s=20.0):
         sample = "%d forward limb-NTTs of the bench batch, N=2^%d" % (n, logN)
     res = {"value": units / t_used, "unit": unit, "cores": 1, "kind": "port", "sample": sample}
     # second figure: one independent unit per host thread (the C checker releases the GIL), bounded like the first
+    if workload in ("encode", "decode"):
+        res["all_cores"] = {"note": "not measured: the encoder's checker is numpy/Python (oracle/encoder.py) and holds the interpreter lock"}
+        return res
     try:
         from concurrent.futures import ThreadPoolExecutor
         T = max(1, min(16, os.cpu_count() or 1))
@@ -356,6 +364,26 @@ class Setup:
                     self.step = lambda: ctx.rotate_non_ntt(galois, work, Li, batch=B)
                     self.metric = "power-basis rotation-keyswitch/sec at N=2^%d, Li=K=%d" % (logN, Li)
                     self.inputs["cpu_one"] = lambda o: (lambda i, c=host(ct[:1]), b=host(kb), a=host(ka): o.rotate_non_ntt(c[0, 0], c[0, 1], galois, b, a))
+            elif workload in ("encode", "decode"):
+                scale = 2.0 ** 50
+                vals = (torch.rand((B, N // 2), dtype=torch.float64, device="cuda", generator=gen) * 8 - 4).to(torch.complex128)
+                vals = vals + 1j * (torch.rand((B, N // 2), dtype=torch.float64, device="cuda", generator=gen) * 8 - 4)
+                msg = torch.zeros((B, Li, N), dtype=torch.int64, device="cuda")
+                ctx.encode(msg, vals, Li, scale, batch=B)
+                pr_li = self.primes[:Li]
+
+                def enc_oracle(o):  # the numpy/Python restatement of the reference's Encoder (oracle/encoder.py)
+                    from oracle.encoder import EncoderOracle
+                    e, v0, m0 = EncoderOracle(logN), vals[0].cpu().numpy(), host(msg[:1])[0]
+                    return (lambda i: e.encode(v0, scale, pr_li)) if workload == "encode" else (lambda i: e.decode(m0, pr_li, scale))
+                if workload == "encode":
+                    self.step = lambda: ctx.encode(msg, vals, Li, scale, batch=B)
+                    self.metric = "Encoder::encode/sec at N=2^%d, %d limbs (complex double FFT + rounding, on the device)" % (logN, Li)
+                else:
+                    slots = torch.zeros((B, N // 2), dtype=torch.complex128, device="cuda")
+                    self.step = lambda: ctx.decode(slots, msg, Li, scale, batch=B)
+                    self.metric = "Encoder::decode/sec at N=2^%d, %d limbs (CRT lift + complex double FFT, on the device)" % (logN, Li)
+                self.inputs["cpu_one"] = enc_oracle
             elif workload == "dec":
                 ct, sx = rnd(B, 2, Li, N), key(L, N)
                 out = torch.empty((B, Li, N), dtype=torch.int64, device="cuda")
@@ -588,7 +616,7 @@ def main():
     result = {
         "metric": su.metric, "value": value, "unit": su.unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64", "data": "synthetic",
+        "dtype": "f64 (complex) + u64" if args.workload in ("encode", "decode") else "u64", "data": "synthetic",
         "config": {"workload": "%s: N=2^%d Li=%d K=%d, %d units/step/GPU" % (args.workload, logN, Li, K, su.per_step_units),
                    "primes": "k*2^32+1 table (SP kernels)" if args.primes == "sp" else "generic 62-bit primes (generic-prime kernels)",
                    "parallelism": "independent ciphertexts sharded over %d GPU(s), no data-path collective" % world},

@@ -4,10 +4,12 @@
 #include "../../include/fhe_hip.h"
 #include "ntt_kernels.h"
 #include "pointwise_kernels.h"
+#include "encoder_kernels.h"
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <algorithm>
 #include <condition_variable>
 #include <map>
@@ -67,6 +69,11 @@ struct fhe_hip_ctx {
   u64 *d_hat_qj_inv_m = nullptr;                 // [L-1][L]     mod q_j
   u64 *d_hat_qj_pi_m = nullptr;                  // [L-1][K][L]  mod p_k, times 2^128
   u64 *d_qinv_m = nullptr;                       // [M][M]: (P[a]^-1 mod P[j]) Montgomery, row a
+  // encoder (fhe_hip_encode / _decode), built on first use: psi^brv(i) as complex doubles, the generator-3 slot index map, and the
+  // Garner constants of the CRT lift over the normal primes
+  cplx *d_enc_roots = nullptr; u32 *d_enc_map = nullptr;
+  u64 *d_enc_qmod_m = nullptr, *d_enc_ginv_m = nullptr; double *d_enc_qd = nullptr;
+  std::map<u32, u64 *> enc_half;   // limb count n -> mixed-radix digits of floor(q_0 .. q_{n-1} / 2)
   // keys
   u64 *d_mk_beta = nullptr, *d_mk_alpha = nullptr;  // [L][L][N] Montgomery form
   std::map<u64, RotKeyDev> rot_keys;
@@ -852,6 +859,8 @@ void fhe_hip_ctx_destroy(fhe_hip_ctx *c) {
   for (auto &kv : c->rot_keys) { hipFree(kv.second.beta_m); hipFree(kv.second.alpha_m); }
   for (auto &kv : c->mixed_keys) { hipFree(kv.second.beta_m); hipFree(kv.second.alpha_m); }
   for (auto &kv : c->galois_perm) hipFree(kv.second);
+  for (auto &kv : c->enc_half) hipFree(kv.second);
+  { void *enc[] = {c->d_enc_roots, c->d_enc_map, c->d_enc_qmod_m, c->d_enc_ginv_m, c->d_enc_qd}; for (void *p : enc) if (p) hipFree(p); }
   for (void *p : c->ws) if (p) hipFree(p);
   for (void *p : c->stage) if (p) hipFree(p);
   if (c->d_idx) hipFree(c->d_idx);
@@ -1632,6 +1641,142 @@ int fhe_hip_encrypt(fhe_hip_ctx *c, uint64_t *ct, const uint64_t *u, const uint6
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   return FHE_HIP_OK;
+  } catch (...) { return abi_exception(); }
+}
+
+}  // extern "C"
+
+// ---- Encoder: reference include/fHE/encoder.hpp:31-45, src/encoder.cpp ---------------------------------
+namespace {
+int ensure_encoder_tables(fhe_hip_ctx *c) {
+  if (c->d_enc_roots) return FHE_HIP_OK;
+  const u64 N = c->N; const u32 logN = c->logN, L = c->L;
+  std::vector<cplx> roots(N);
+  std::vector<u32> map(N);
+  const long double two_pi = 6.283185307179586476925286766559005768L;
+  for (u64 i = 0; i < N; ++i) {  // roots_[i] = psi^brv(i), psi = exp(2 pi i / 2N)  (encoder.cpp:27-33)
+    const long double ang = two_pi * (long double)h_brv(i, logN) / (long double)(2 * N);
+    roots[i] = make_double2((double)cosl(ang), (double)sinl(ang));
+  }
+  u64 pos = 1;
+  for (u64 i = 0; i < N / 2; ++i) {  // encoder.cpp:9-25
+    map[i] = (u32)h_brv((pos - 1) >> 1, logN);
+    map[N / 2 + i] = (u32)h_brv((2 * N - pos - 1) >> 1, logN);
+    pos = (pos * 3) & (2 * N - 1);
+  }
+  std::vector<u64> qmod((size_t)L * L, 0), ginv(L, 0);
+  std::vector<double> qd(L);
+  const std::vector<u64> &P = c->primes;
+  for (u32 k = 0; k < L; ++k) {
+    qd[k] = (double)P[k];
+    u64 prod = 1;
+    for (u32 j = 0; j < k; ++j) { qmod[(size_t)k * L + j] = h_to_mont(P[j] % P[k], P[k]); prod = h_mulmod(prod, P[j] % P[k], P[k]); }
+    if (k) ginv[k] = h_to_mont(h_invmod(prod, P[k]), P[k]);
+  }
+  int rc;
+  if ((rc = upload(c, &c->d_enc_map, map)) || (rc = upload(c, &c->d_enc_qmod_m, qmod)) || (rc = upload(c, &c->d_enc_ginv_m, ginv)) ||
+      (rc = upload(c, &c->d_enc_qd, qd)) || (rc = upload(c, &c->d_enc_roots, roots))) return rc;
+  return FHE_HIP_OK;
+}
+// mixed-radix digits of floor(Q_n / 2), Q_n = q_0 .. q_{n-1}: exact multi-word arithmetic on the host, once per limb count
+int ensure_half_digits(fhe_hip_ctx *c, u32 n, const u64 **out) {
+  auto it = c->enc_half.find(n);
+  if (it != c->enc_half.end()) { *out = it->second; return FHE_HIP_OK; }
+  std::vector<u64> big{1};
+  for (u32 k = 0; k < n; ++k) {  // big *= q_k
+    u128 carry = 0;
+    for (auto &w : big) { carry += (u128)w * c->primes[k]; w = (u64)carry; carry >>= 64; }
+    if (carry) big.push_back((u64)carry);
+  }
+  { u64 carry = 0; for (size_t i = big.size(); i-- > 0;) { const u64 w = big[i]; big[i] = (w >> 1) | (carry << 63); carry = w & 1; } }
+  std::vector<u64> digits(n);
+  for (u32 k = 0; k < n; ++k) {  // digit = big mod q_k, big /= q_k
+    u128 rem = 0;
+    for (size_t i = big.size(); i-- > 0;) { const u128 cur = (rem << 64) | big[i]; big[i] = (u64)(cur / c->primes[k]); rem = cur % c->primes[k]; }
+    digits[k] = (u64)rem;
+  }
+  u64 *d = nullptr;
+  TRY(upload(c, &d, digits));
+  c->enc_half[n] = d;
+  *out = d;
+  return FHE_HIP_OK;
+}
+template <bool INV> int enc_fft(fhe_hip_ctx *c, cplx *w, u32 batch) {
+  const u32 R = 1u << c->logR;
+  const size_t smem = (size_t)R * ENC_CT * sizeof(cplx);
+  if constexpr (INV) {
+    LAUNCH(c, "enc_ifft_rows", (enc_fft_rows_kernel<true>), dim3(R / 2, batch), dim3(256), w, (const cplx *)c->d_enc_roots, c->logN);
+    hipEvent_t ev0_ = nullptr;  // (dynamic LDS: launched by hand, timed like LAUNCH)
+    if (c->prof && !c->fixed_ws) ev0_ = c->chain_valid ? c->chain_ev : prof_event(c);
+    hipLaunchKernelGGL((enc_fft_cols_kernel<true>), dim3(256 / ENC_CT, batch), dim3(256), smem, c->stream, w, (const cplx *)c->d_enc_roots, c->logN);
+    if (c->prof && !c->fixed_ws) { c->chain_ev = prof_event(c); c->chain_valid = true; prof_entry(c, "enc_ifft_cols")->pending.push_back({ev0_, c->chain_ev}); }
+    HIPCHK(c, hipGetLastError());
+  } else {
+    hipEvent_t ev0_ = nullptr;
+    if (c->prof && !c->fixed_ws) ev0_ = c->chain_valid ? c->chain_ev : prof_event(c);
+    hipLaunchKernelGGL((enc_fft_cols_kernel<false>), dim3(256 / ENC_CT, batch), dim3(256), smem, c->stream, w, (const cplx *)c->d_enc_roots, c->logN);
+    if (c->prof && !c->fixed_ws) { c->chain_ev = prof_event(c); c->chain_valid = true; prof_entry(c, "enc_fft_cols")->pending.push_back({ev0_, c->chain_ev}); }
+    HIPCHK(c, hipGetLastError());
+    LAUNCH(c, "enc_fft_rows", (enc_fft_rows_kernel<false>), dim3(R / 2, batch), dim3(256), w, (const cplx *)c->d_enc_roots, c->logN);
+  }
+  return FHE_HIP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int fhe_hip_encode(fhe_hip_ctx *c, uint64_t *msg, const double *values, size_t nvals, uint32_t nlimbs, double scale, size_t batch, int mem_kind) {
+  try {
+  TRY(check_ctx(c));
+  if (!msg || (!values && nvals)) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (nlimbs < 1 || nlimbs > c->L) FAIL(c, FHE_HIP_ERR_RANGE, "bad limb count");
+  if (!(scale > 0.0) || !std::isfinite(scale)) FAIL(c, FHE_HIP_ERR_ARG, "scale must be positive and finite");
+  if (batch == 0) return FHE_HIP_OK;
+  if (batch > 65535) FAIL(c, FHE_HIP_ERR_RANGE, "batch too large for one call");
+  const u64 N = c->N;
+  const size_t used = nvals < N / 2 ? nvals : N / 2;  // "Just handle the first nr_slots values" (encoder.cpp:87-91)
+  TRY(ensure_encoder_tables(c));
+  TRY(ensure_ws(c, 5, batch * N * sizeof(cplx)));
+  cplx *w = (cplx *)c->ws[5];
+  Staged st(c, mem_kind);
+  const u64 *dvals = nullptr; u64 *dmsg = nullptr;
+  if (nvals) TRY(st.in(values, batch * nvals * sizeof(cplx), &dvals));
+  TRY(st.out(msg, batch * nlimbs * N * 8, &dmsg, false));
+  HIPCHK(c, (prof_chain_break(c), hipMemsetAsync(w, 0, batch * N * sizeof(cplx), c->stream)));
+  if (used) LAUNCH(c, "enc_scatter", enc_scatter_kernel, dim3((unsigned)((used + 255) / 256), (unsigned)batch), dim3(256), w, (const cplx *)dvals,
+                   (const u32 *)c->d_enc_map, N, (u64)nvals);
+  TRY((enc_fft<true>(c, w, (u32)batch)));
+  LAUNCH(c, "enc_round", enc_round_kernel, dim3((unsigned)(N / 256), (unsigned)batch), dim3(256), dmsg, (const cplx *)w, (const PrimeC *)c->d_primes, nlimbs, N,
+         scale / (double)N);
+  return st.finish();
+  } catch (...) { return abi_exception(); }
+}
+
+int fhe_hip_decode(fhe_hip_ctx *c, double *slots, const uint64_t *msg, uint32_t nlimbs, double scale, size_t batch, int mem_kind) {
+  try {
+  TRY(check_ctx(c));
+  if (!slots || !msg) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
+  if (nlimbs < 1 || nlimbs > c->L || nlimbs > DEC_MAX_LIMBS) FAIL(c, FHE_HIP_ERR_RANGE, "bad limb count");
+  if (!(scale > 0.0) || !std::isfinite(scale)) FAIL(c, FHE_HIP_ERR_ARG, "scale must be positive and finite");
+  if (batch == 0) return FHE_HIP_OK;
+  if (batch > 65535) FAIL(c, FHE_HIP_ERR_RANGE, "batch too large for one call");
+  const u64 N = c->N;
+  TRY(ensure_encoder_tables(c));
+  const u64 *half = nullptr;
+  TRY(ensure_half_digits(c, nlimbs, &half));
+  TRY(ensure_ws(c, 5, batch * N * sizeof(cplx)));
+  cplx *w = (cplx *)c->ws[5];
+  Staged st(c, mem_kind);
+  const u64 *dmsg = nullptr; u64 *dslots = nullptr;
+  TRY(st.in(msg, batch * nlimbs * N * 8, &dmsg));
+  TRY(st.out(slots, batch * (N / 2) * sizeof(cplx), &dslots, false));
+  DecLiftArgs a;
+  a.w = w; a.msg = dmsg; a.primes = c->d_primes; a.qmod_m = c->d_enc_qmod_m; a.ginv_m = c->d_enc_ginv_m; a.half = half; a.qd = c->d_enc_qd;
+  a.n = nlimbs; a.L = c->L; a.N = N; a.inv_scale = 1.0 / scale;
+  LAUNCH_SP(c, "dec_lift", dec_lift_kernel, dim3((unsigned)(N / 256), (unsigned)batch), dim3(256), a);
+  TRY((enc_fft<false>(c, w, (u32)batch)));
+  LAUNCH(c, "dec_pick", dec_pick_kernel, dim3((unsigned)((N / 2 + 255) / 256), (unsigned)batch), dim3(256), (cplx *)dslots, (const cplx *)w, (const u32 *)c->d_enc_map, N);
+  return st.finish();
   } catch (...) { return abi_exception(); }
 }
 

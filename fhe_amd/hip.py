@@ -72,6 +72,8 @@ def load_library():
         "fhe_hip_mem_alloc": (i, [vp, C.POINTER(vp), sz]),
         "fhe_hip_mem_free": (i, [vp, vp]),
         "fhe_hip_mem_copy": (i, [vp, vp, vp, sz, i]),
+        "fhe_hip_encode": (i, [vp, vp, vp, sz, u32, C.c_double, sz, i]),
+        "fhe_hip_decode": (i, [vp, vp, vp, u32, C.c_double, sz, i]),
         "fhe_hip_load_mult_key": (i, [vp, vp, vp, i]),
         "fhe_hip_load_rot_key": (i, [vp, u64, vp, vp, i]),
         "fhe_hip_add": (i, [vp, vp, vp, u32, sz, i]),
@@ -109,7 +111,7 @@ EXPORTED_SYMBOLS = [
     "fhe_hip_add", "fhe_hip_multiply_plain", "fhe_hip_cross_mult", "fhe_hip_relin_only", "fhe_hip_relinearize",
     "fhe_hip_mul_relin_rescale", "fhe_hip_rotate", "fhe_hip_rotate_non_ntt", "fhe_hip_load_mixed_rot_key", "fhe_hip_rotate_mixed", "fhe_hip_decrypt", "fhe_hip_encrypt", "fhe_hip_profile_enable", "fhe_hip_profile_reset",
     "fhe_hip_profile_get", "fhe_hip_batch_run", "fhe_hip_conv_to_normal", "fhe_hip_mul_relin_rescale_noalloc", "fhe_hip_set_tuning", "fhe_hip_debug_violations", "fhe_hip_rotate_to",
-    "fhe_hip_conv_to_special", "fhe_hip_mem_alloc", "fhe_hip_mem_free", "fhe_hip_mem_copy",
+    "fhe_hip_conv_to_special", "fhe_hip_mem_alloc", "fhe_hip_mem_free", "fhe_hip_mem_copy", "fhe_hip_encode", "fhe_hip_decode",
 ]
 OP_MUL_RELIN_RESCALE, OP_ROTATE, OP_ROTATE_MIXED, OP_ROTATE_NON_NTT = 1, 2, 3, 4
 TUNE_RELIN_GROUP = 1
@@ -129,6 +131,20 @@ def _buf(x):
     if isinstance(x, torch.Tensor):
         if not x.is_cuda or x.dtype != torch.int64 or not x.is_contiguous():
             raise TypeError("device buffers must be contiguous CUDA int64 tensors")
+        return x.data_ptr(), MEM_DEVICE
+    raise TypeError("unsupported buffer type %r" % type(x))
+
+
+def _cbuf(x):
+    """-> (pointer, mem_kind) for complex slot values: a C-contiguous numpy complex128 array or a contiguous CUDA complex128 tensor."""
+    if isinstance(x, np.ndarray):
+        if x.dtype != np.complex128 or not x.flags["C_CONTIGUOUS"]:
+            raise TypeError("host slot buffers must be C-contiguous numpy complex128 arrays")
+        return x.ctypes.data, MEM_HOST
+    import torch
+    if isinstance(x, torch.Tensor):
+        if not x.is_cuda or x.dtype != torch.complex128 or not x.is_contiguous():
+            raise TypeError("device slot buffers must be contiguous CUDA complex128 tensors")
         return x.data_ptr(), MEM_DEVICE
     raise TypeError("unsupported buffer type %r" % type(x))
 
@@ -253,6 +269,32 @@ class HipContext:
         _need(rop=(rop, batch * self.N), op=(op, batch * Li * self.N))
         self._chk(self.lib.fhe_hip_conv_to_special(self.h, r, o, Li, sp_index, batch, kind))
         return rop
+
+    # ---- encoder ---------------------------------------------------------
+    def encode(self, msg, values, nlimbs, scale, batch=1):
+        """Encoder::encode (src/encoder.cpp:84-157): values = [batch][nvals] complex128 -> msg = [batch][nlimbs][N], power basis."""
+        vp_, vk = _cbuf(values)
+        (m,), kind = _same_kind(msg)
+        if vk != kind:
+            raise TypeError("all buffers of one call must live on the same side (all host or all device)")
+        nvals = _count(values) // batch
+        if nvals * batch != _count(values):
+            raise ValueError("values must hold batch * nvals entries")
+        _need(msg=(msg, batch * nlimbs * self.N))
+        self._chk(self.lib.fhe_hip_encode(self.h, m, vp_, nvals, nlimbs, float(scale), batch, kind))
+        return msg
+
+    def decode(self, slots, msg, nlimbs, scale, batch=1):
+        """Encoder::decode (src/encoder.cpp:159-200): msg = [batch][nlimbs][N] power basis -> slots = [batch][N/2] complex128."""
+        sp_, sk = _cbuf(slots)
+        (m,), kind = _same_kind(msg)
+        if sk != kind:
+            raise TypeError("all buffers of one call must live on the same side (all host or all device)")
+        if _count(slots) < batch * (self.N // 2):
+            raise ValueError("slots holds %d values, the call writes %d" % (_count(slots), batch * (self.N // 2)))
+        _need(msg=(msg, batch * nlimbs * self.N))
+        self._chk(self.lib.fhe_hip_decode(self.h, sp_, m, nlimbs, float(scale), batch, kind))
+        return slots
 
     # ---- keys -------------------------------------------------------------------------------
     def load_mult_key(self, beta, alpha):

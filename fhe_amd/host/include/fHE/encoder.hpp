@@ -1,7 +1,7 @@
 // fHE/encoder.hpp — host Encoder with the reference's public shape (include/fHE/encoder.hpp:6-46):
-// CKKS canonical-embedding encoder.  Floating point, host only; it exists so that Evaluator::replicate (which encodes a
-// slot mask) and full pipelines can run on the mirror.  The reference goes through GMP (mpz_set_d / mpz_mod_ui /
-// poly2mpz); here the same integers are formed with 128-bit and small multi-word arithmetic (no GMP dependency).
+// CKKS canonical-embedding encoder.  encode / decode run on the GPU through the C-ABI (floating point: complex double, like the
+// reference); a host implementation of the same mathematics is kept beside them as a cross-check.  The reference goes through GMP
+// (mpz_set_d / mpz_mod_ui / poly2mpz); neither path here needs it.
 #pragma once
 #include "fHE/context.hpp"
 #include <algorithm>
@@ -122,7 +122,32 @@ struct Encoder {
   }
   ~Encoder() {}
 
+  // The public encode / decode run on the GPU (fhe_hip_encode / fhe_hip_decode: the reference's butterfly networks in complex
+  // double, rounding and CRT lift as device kernels); the plaintext polynomial stays in device memory until somebody reads it on
+  // the host.  The host implementations below (a different route to the same numbers: twist + cyclic DFT, multi-word CRT) are
+  // kept as an independent cross-check of the device path (fhe_amd/host/test/host_roundtrip.cpp); nothing falls back to them.
   void encode(context::poly_t *msg, std::vector<cplx> const &values, const double scale = context::encoder_scale) const {  // encoder.cpp:116-147
+    if (!msg) return;
+    const size_t nm = msg->moduli_count();
+    if (values.size() > nr_slots) std::cerr << "WARN: Too many values to encode." << "Just handle the first " << nr_slots << " values.\n";
+    fhe_hip_ctx *ctx = yell::runtime::get().ctx;
+    const size_t nvals = std::min(values.size(), nr_slots);
+    auto out = std::make_shared<yell::dev_block>(ctx, nm * degree);
+    auto in = std::make_shared<yell::dev_block>(ctx, 2 * std::max<size_t>(nvals, 1));
+    if (nvals) yell::check(fhe_hip_mem_copy(ctx, in->p, values.data(), nvals * sizeof(cplx), FHE_HIP_COPY_H2D), "encode: slots -> device");
+    yell::check(fhe_hip_encode(ctx, out->p, reinterpret_cast<const double *>(in->p), nvals, (uint32_t)nm, scale, 1, FHE_HIP_MEM_DEVICE), "encode");
+    msg->adopt(out, 0, nm);
+  }
+  void decode(std::vector<cplx> *rop, context::poly_t const &msg, double scale_) const {  // encoder.cpp:159-188
+    if (!rop) return;
+    fhe_hip_ctx *ctx = yell::runtime::get().ctx;
+    auto out = std::make_shared<yell::dev_block>(ctx, 2 * nr_slots);
+    yell::check(fhe_hip_decode(ctx, reinterpret_cast<double *>(out->p), msg.cdev(), (uint32_t)msg.moduli_count(), scale_, 1, FHE_HIP_MEM_DEVICE), "decode");
+    rop->resize(nr_slots);
+    yell::check(fhe_hip_mem_copy(ctx, rop->data(), out->p, nr_slots * sizeof(cplx), FHE_HIP_COPY_D2H), "decode: slots -> host");
+  }
+
+  void encode_on_host(context::poly_t *msg, std::vector<cplx> const &values, const double scale = context::encoder_scale) const {
     if (!msg) return;
     const std::vector<cplx> conj_values{coefficients_times_n(values)};
     const double delta = scale / (double)degree;
@@ -138,7 +163,7 @@ struct Encoder {
     encode(msg, com_values, scale);
   }
 
-  void decode(std::vector<cplx> *rop, context::poly_t const &msg, double scale_) const {  // encoder.cpp:159-188
+  void decode_on_host(std::vector<cplx> *rop, context::poly_t const &msg, double scale_) const {
     if (!rop) return;
     const size_t nmoduli = msg.moduli_count();
     // Garner mixed radix: x = v0 + v1 q0 + v2 q0 q1 + ...

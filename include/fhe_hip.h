@@ -182,6 +182,16 @@ int fhe_hip_batch_run(fhe_hip_ctx *const *ctxs, uint32_t n_ctx, int op, uint64_t
 #define FHE_HIP_NOALLOC_SCRATCH_BYTES (256u << 20)
 int fhe_hip_mul_relin_rescale_noalloc(fhe_hip_ctx *ctx, uint64_t *out, const uint64_t *c0, const uint64_t *c1, uint32_t Li, size_t batch);
 
+/* Encoder::encode (include/fHE/encoder.hpp:31-37, src/encoder.cpp:84-157): values = [batch][nvals] complex doubles (re, im
+ * interleaved; real inputs have im = 0), the first min(nvals, N/2) of each entry are used like the reference's ("Just handle the
+ * first nr_slots values") -> msg = [batch][nlimbs][N], power basis, limb l under P[l]:
+ * coefficient = trunc(Re(iFFT(slots through the generator-3 index map))[d] * scale / N) mod P[l], non-negative remainder
+ * (mpz_set_d + mpz_mod_ui).  Floating point (complex double, like the reference): results agree with a CPU run to rounding.
+ * Encoder::decode (encoder.hpp:39-45, encoder.cpp:159-200): msg = [batch][nlimbs][N] power basis -> slots = [batch][N/2] complex
+ * doubles: CRT lift to [0, Q), centred around Q/2, divided by scale, FFT, slots picked through the index map. */
+int fhe_hip_encode(fhe_hip_ctx *ctx, uint64_t *msg, const double *values, size_t nvals, uint32_t nlimbs, double scale, size_t batch, int mem_kind);
+int fhe_hip_decode(fhe_hip_ctx *ctx, double *slots, const uint64_t *msg, uint32_t nlimbs, double scale, size_t batch, int mem_kind);
+
 /* Runtime tuning (the reference has compile-time constants only, include/fHE/context.hpp:7-14).
  *   FHE_HIP_TUNE_RELIN_GROUP: output limbs per relinearisation pass (0 = all at once, the default).  The column-pass output
  *   of the Li^2 digit NTTs is produced and consumed value limbs at a time, which bounds its footprint to

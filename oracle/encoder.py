@@ -71,12 +71,15 @@ class EncoderOracle:
         Q = 1
         for p in primes:
             Q *= p
+        # CRT constants once per call (same integers as recomputing them per coefficient)
+        Qk = [Q // p for p in primes]
+        term = [Qk[k] * pow(Qk[k], -1, p) for k, p in enumerate(primes)]
+        cols = [[int(v) for v in limbs[k]] for k in range(len(primes))]
         coef = []
         for i in range(self.N):
             x = 0
-            for k, p in enumerate(primes):
-                Qk = Q // p
-                x += int(limbs[k][i]) * pow(Qk, -1, p) % p * Qk
+            for k in range(len(primes)):
+                x += cols[k][i] * term[k]
             x %= Q
             if x >= Q // 2:
                 x -= Q
