@@ -92,6 +92,9 @@ struct fhe_hip_ctx {
   unsigned char *scratch = nullptr;
   bool fixed_ws = false; size_t fixed_used = 0;
   uint32_t relin_group = 0;  // output limbs per relinearisation pass (0 = all Li at once): fhe_hip_set_tuning
+  uint32_t relin4 = 1;       // digit key switch with unreduced key-MAC accumulators (relin_rows4_mac_kernel); 0: the Montgomery-MAC kernel
+  bool mk_128 = false;       // the MultKey / MixedRotKey copies are stored times 2^128 (relin4's form) instead of times 2^64
+  std::map<u64, bool> mixed_128;
   int num_cus = 256;         // persistent kernels size their grids by it
   uint32_t onepass = 1;      // N = 2^12 .. 2^14: plain NTTs as one kernel with the limb in LDS (FHE_HIP_TUNE_ONEPASS)
   uint32_t ntt_chunk = 0;    // limbs per pass pair of fhe_hip_ntt_forward / _backward (0 = as many as one grid takes)
@@ -500,7 +503,12 @@ int run_digit_keyswitch(fhe_hip_ctx *c, RelinArgs ra, const u64 *pw, u64 *t1, co
     pf.l0 = i0 * nd; pf.skip_diag = nd; pf.cols_only = true;
     TRY(ntt_run(c, pf, false));
     ra.i0 = i0; ra.gi = gi;
-    LAUNCH_SP(c, "relin_rows_mac", relin_rows8p_mac_kernel, dim3(nb * ra.rb_count * gi), dim3(32 * rows), ra);
+    if (c->relin4) {
+      ra.rb_count = R / 4;   // four rows per workgroup, one wave each
+      LAUNCH_SP(c, "relin_rows_mac", relin_rows4_mac_kernel, dim3(nb * ra.rb_count * gi), dim3(256), ra);
+    } else {
+      LAUNCH_SP(c, "relin_rows_mac", relin_rows8p_mac_kernel, dim3(nb * ra.rb_count * gi), dim3(32 * rows), ra);
+    }
   }
   return FHE_HIP_OK;
 }
@@ -509,6 +517,7 @@ int run_digit_keyswitch(fhe_hip_ctx *c, RelinArgs ra, const u64 *pw, u64 *t1, co
 int dev_relin(fhe_hip_ctx *c, u64 *out, const u64 *ct3, u32 Li, u32 batch) {
   const u64 N = c->N;
   if (!c->d_mk_beta) FAIL(c, FHE_HIP_ERR_NOKEY, "mult key not loaded");
+  if (c->mk_128 != (c->relin4 != 0)) FAIL(c, FHE_HIP_ERR_NOKEY, "mult key was loaded for the other relinearisation kernel (FHE_HIP_TUNE_RELIN_KERNEL): load it again");
   u32 group = c->relin_group ? (c->relin_group < Li ? c->relin_group : Li) : Li;
   u32 chunk = batch;
   if (c->fixed_ws) {
@@ -686,6 +695,7 @@ int dev_rotate_mixed(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch) {
   const u64 N = c->N; const u32 nout = Li + 1;
   auto it = c->mixed_keys.find(galois);
   if (it == c->mixed_keys.end()) FAIL(c, FHE_HIP_ERR_NOKEY, "mixed rotation key not loaded for this galois element");
+  if (c->mixed_128[galois] != (c->relin4 != 0)) FAIL(c, FHE_HIP_ERR_NOKEY, "mixed rotation key was loaded for the other key-switch kernel (FHE_HIP_TUNE_RELIN_KERNEL): load it again");
   const size_t ctb = (size_t)batch * 2 * Li * N * 8;
   TRY(ensure_ws(c, 3, ctb));                                       // g = galois(ct)
   TRY(ensure_ws(c, 0, (size_t)batch * Li * N * 8));                // power basis of the digits
@@ -1110,11 +1120,13 @@ int fhe_hip_rescale(fhe_hip_ctx *c, uint64_t *rop, const uint64_t *op, uint32_t 
   } catch (...) { return abi_exception(); }
 }
 
-static int load_key(fhe_hip_ctx *c, u64 **dst, const uint64_t *src, size_t limbs, const u32 *midx, u32 mper, int mem_kind) {
+// key copy in Montgomery form (times 2^64), or times 2^128 for the kernel whose fold divides by 2^128 (relin_rows4_mac_kernel)
+static int load_key(fhe_hip_ctx *c, u64 **dst, const uint64_t *src, size_t limbs, const u32 *midx, u32 mper, int mem_kind, bool twice = false) {
   const size_t bytes = limbs * c->N * 8;
   if (!*dst) HIPCHK(c, hipMalloc((void **)dst, bytes));
   HIPCHK(c, (prof_chain_break(c), hipMemcpyAsync(*dst, src, bytes, mem_kind == FHE_HIP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream)));
-  LAUNCH_SP(c, "to_mont", to_mont_kernel, pw_grid(c, (u32)limbs, 1), dim3(PW_THREADS), *dst, (const PrimeC *)c->d_primes, midx, mper, c->N);
+  for (int k = 0; k < (twice ? 2 : 1); ++k)
+    LAUNCH_SP(c, "to_mont", to_mont_kernel, pw_grid(c, (u32)limbs, 1), dim3(PW_THREADS), *dst, (const PrimeC *)c->d_primes, midx, mper, c->N);
   return FHE_HIP_OK;
 }
 
@@ -1123,8 +1135,9 @@ int fhe_hip_load_mult_key(fhe_hip_ctx *c, const uint64_t *beta, const uint64_t *
   TRY(check_ctx(c));
   if (!beta || !alpha) FAIL(c, FHE_HIP_ERR_ARG, "null argument");
   // [L][L][N]: limb id = j*L + i uses modulus i = id % L
-  TRY(load_key(c, &c->d_mk_beta, beta, (size_t)c->L * c->L, c->d_iota, c->L, mem_kind));
-  TRY(load_key(c, &c->d_mk_alpha, alpha, (size_t)c->L * c->L, c->d_iota, c->L, mem_kind));
+  TRY(load_key(c, &c->d_mk_beta, beta, (size_t)c->L * c->L, c->d_iota, c->L, mem_kind, c->relin4 != 0));
+  TRY(load_key(c, &c->d_mk_alpha, alpha, (size_t)c->L * c->L, c->d_iota, c->L, mem_kind, c->relin4 != 0));
+  c->mk_128 = c->relin4 != 0;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return FHE_HIP_OK;
   } catch (...) { return abi_exception(); }
@@ -1291,6 +1304,7 @@ int fhe_hip_set_tuning(fhe_hip_ctx *c, int knob, uint64_t value) {
   if (knob == FHE_HIP_TUNE_RELIN_GROUP) { c->relin_group = value > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)value; return FHE_HIP_OK; }
   if (knob == FHE_HIP_TUNE_ONEPASS) { c->onepass = value ? 1u : 0u; return FHE_HIP_OK; }
   if (knob == FHE_HIP_TUNE_NTT_CHUNK) { c->ntt_chunk = value > 32768 ? 32768u : (uint32_t)value; return FHE_HIP_OK; }
+  if (knob == FHE_HIP_TUNE_RELIN_KERNEL) { c->relin4 = value ? 1u : 0u; return FHE_HIP_OK; }
   if (knob == FHE_HIP_TUNE_NTT_STREAMS) { c->ntt_streams = value >= 2 ? 2u : 1u; return FHE_HIP_OK; }
   FAIL(c, FHE_HIP_ERR_ARG, "unknown tuning knob");
 }
@@ -1549,8 +1563,9 @@ int fhe_hip_load_mixed_rot_key(fhe_hip_ctx *c, uint64_t galois, const uint64_t *
   if (galois != 0 && (!(galois & 1) || galois >= 2 * c->N)) FAIL(c, FHE_HIP_ERR_ARG, "galois must be odd and < 2N");
   MixedRotKeyDev &rk = c->mixed_keys[galois];
   // [L][L+1][N]: limb id = i*(L+1) + j uses modulus j = id % (L+1) (limb L is the special prime P[L])
-  TRY(load_key(c, &rk.beta_m, beta, (size_t)c->L * (c->L + 1), c->d_iota, c->L + 1, mem_kind));
-  TRY(load_key(c, &rk.alpha_m, alpha, (size_t)c->L * (c->L + 1), c->d_iota, c->L + 1, mem_kind));
+  TRY(load_key(c, &rk.beta_m, beta, (size_t)c->L * (c->L + 1), c->d_iota, c->L + 1, mem_kind, c->relin4 != 0));
+  TRY(load_key(c, &rk.alpha_m, alpha, (size_t)c->L * (c->L + 1), c->d_iota, c->L + 1, mem_kind, c->relin4 != 0));
+  c->mixed_128[galois] = c->relin4 != 0;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return FHE_HIP_OK;
   } catch (...) { return abi_exception(); }

@@ -14,6 +14,7 @@
 // For N <= 2^14 a limb fits one workgroup's LDS and plain transforms run as ONE kernel (ntt_onepass_*, end of this file).
 #pragma once
 #include "modarith.h"
+#include <type_traits>
 
 struct NttArgs {
   const u64 *src;       // source limbs
@@ -751,6 +752,236 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     DBG_RANGE(r00, P.p, 10); DBG_RANGE(r01, P.p, 10); DBG_RANGE(r10, P.p, 10); DBG_RANGE(r11, P.p, 10);
     *reinterpret_cast<ulonglong2 *>(&o[e]) = make_ulonglong2(r00, r01);
     *reinterpret_cast<ulonglong2 *>(&o[half + e]) = make_ulonglong2(r10, r11);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Same fused relinearisation row pass with the key products accumulated WITHOUT reduction (round 3).  A Montgomery key MAC costs
+// 16 issue slots (11 for the product, 5 to keep the accumulator below 4p); here a MAC is its 6 multiply-adds and nothing else:
+// the lazy NTT output x (< 2^64) is cut once into three 22-bit limbs (shared by the beta and the alpha product), the key word
+// pair (k0, k1) multiplies each limb, and every one of the six partial products (< 2^54) is added into a 64-bit accumulator of
+// its own by the multiply-add that forms it (room for 2^8 digits).  The six sums are folded once per output coefficient, after
+// the digit loop (relin_fold: integer shifts and adds to the 134-bit sum, then two 64-bit Montgomery reductions, i.e. * 2^-128;
+// the keys of this kernel are stored times 2^128 mod p, so the result is the plain residue).
+// 96 accumulator registers per thread allow 4 coefficients per thread: 64 threads (one wave) per 256-element row, register
+// phases of 2 + 2 + 2 + 2 stages, three wave-local LDS exchanges; a thread ends the row pass with the 4 contiguous coefficients
+// {4t + k} and takes its key words with two 16-byte loads per key, so the MAC needs no exchange at all.
+// ---------------------------------------------------------------------------------------------
+constexpr int ROW4_LDS = 288;
+// element e of a row sits at e + 2 (e >> 4): two pad words per 16 elements (groups of 4 stay 16-byte aligned)
+
+template <bool SP>
+__device__ __forceinline__ u64 relin_fold(const u64 (&A)[6], const PrimeC &PT) {
+  typedef unsigned __int128 u128;
+  const u128 U = (u128)A[0] + ((u128)A[1] << 22) + ((u128)A[2] << 44);  // k0 * x          < 2^104
+  const u128 V = (u128)A[3] + ((u128)A[4] << 22) + ((u128)A[5] << 44);  // k1 * x, weight 2^32
+  const u128 S = U + (V << 32);
+  const u64 X0 = (u64)S, X1 = (u64)(S >> 64);
+  const u64 X2 = (u64)(V >> 96) + (S < U ? 1u : 0u);
+  const u64 r1 = mont_reduce<SP>(0, X0, PT);
+  const u64 w_lo = X1 + r1;
+  const u64 w_hi = X2 + (w_lo < r1 ? 1u : 0u);
+  return csub(mont_reduce<SP>(w_hi, w_lo, PT), PT.p);
+}
+
+template <bool SP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void relin_rows4_mac_kernel(RelinArgs a) {
+  // per wave: two row images (two digits are transformed side by side: four independent butterflies per stage and thread, which
+  // is what keeps the multiply-add pipeline full at two waves per SIMD)
+  __shared__ __attribute__((aligned(16))) u64 lds[4 * 2 * ROW4_LDS];
+  // the wave index is wave-uniform: through readfirstlane, so that everything that depends on the row (addresses of the digit, the
+  // keys, the twiddles) is scalar arithmetic and the loads take a scalar base with a 32-bit lane offset
+  const u32 tid = threadIdx.x, rloc = __builtin_amdgcn_readfirstlane(tid >> 6), t = tid & 63;
+  u32 rb, b, irel;
+  {
+    const u32 id = blockIdx.x, nb = a.nb, RB = a.rb_count;
+    if ((RB & 7) == 0) {
+      const u32 xcd = id & 7, q = id >> 3;
+      b = q % nb;
+      const u32 rest = q / nb;
+      rb = xcd + 8 * (rest % (RB >> 3));
+      irel = rest / (RB >> 3);
+    } else {
+      b = id % nb;
+      rb = (id / nb) % RB;
+      irel = id / (nb * RB);
+    }
+  }
+  const u32 i = a.i0 + irel;
+  const u32 row = rb * 4 + rloc;  // 4 rows per workgroup, one wave each
+  const u32 nd = a.nd;
+  const u32 m = a.omap[i];
+  const PrimeC P = a.primes[m];
+  const u64 N = 1ull << a.logN;
+  u64 *L = lds + rloc * 2 * ROW4_LDS;
+  const u32 baseA = (1u << a.logR) + row;
+  const u64 row_off = (u64)row * 256;
+  const u32 ga = t >> 4, ra = t & 15, gc = t >> 2, rc = t & 3;
+  // the thread's twelve twiddles (three per register phase) are the same for every digit: loaded once, kept in registers
+  u64 wA[3], wB[3], wC[3], wD[3];
+  {
+    const u64 *tw = a.tw + (u64)m * N;
+    load_tw<2>(wA, tw, baseA);
+    load_tw<2>(wB, tw, (baseA << 2) + ga);
+    load_tw<2>(wC, tw, (baseA << 4) + gc);
+    load_tw<2>(wD, tw, (baseA << 6) + t);
+  }
+  u64 acc[4][2][6];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int w = 0; w < 6; ++w) acc[e][h][w] = 0;
+  // LDS positions of the four ownership patterns, row4_pos spelled out as base + constant (immediate offsets):
+  //   {t + 64k} -> pA + 72k;  {64 ga + ra + 16k} -> pB + 18k;  {16 gc + rc + 4k} -> pC + 4k;  {4t + k} -> pD + k
+  u64 *const pA = L + t + 2 * (t >> 4), *const pB = L + 72 * ga + ra, *const pC = L + 18 * gc + rc, *const pD = L + 4 * t + 2 * (t >> 2);
+  struct Keys { ulonglong2 b0, b1, a0, a1; };
+  auto load_keys = [&](u32 j) {
+    const u64 koff = ((u64)j * a.klimbs + m) * N + row_off;   // wave-uniform
+    const u64 *kbp = a.beta_m + koff, *kap = a.alpha_m + koff;
+    Keys k;
+    k.b0 = *reinterpret_cast<const ulonglong2 *>(&kbp[4 * t]); k.b1 = *reinterpret_cast<const ulonglong2 *>(&kbp[4 * t + 2]);
+    k.a0 = *reinterpret_cast<const ulonglong2 *>(&kap[4 * t]); k.a1 = *reinterpret_cast<const ulonglong2 *>(&kap[4 * t + 2]);
+    return k;
+  };
+  auto load_digit = [&](u64 (&v)[4], u32 j) {   // column-pass output of digit j: the thread's {t + 64k}
+    const u64 *s = a.t1 + (((u64)b * a.gi + irel) * nd + j) * N + row_off;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = s[t + 64 * k];
+  };
+  auto mac = [&](const u64 (&x)[4], const Keys &key) {
+    const u64 kb[4] = {key.b0.x, key.b0.y, key.b1.x, key.b1.y}, ka[4] = {key.a0.x, key.a0.y, key.a1.x, key.a1.y};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const u32 xl = (u32)x[e], xh = (u32)(x[e] >> 32);
+      const u32 x0 = xl & 0x3FFFFFu, x1 = ((xl >> 22) | (xh << 10)) & 0x3FFFFFu, x2 = xh >> 12;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const u64 k = h ? ka[e] : kb[e];
+        const u32 k0 = (u32)k, k1 = (u32)(k >> 32);
+        acc[e][h][0] = mad_wide(k0, x0, acc[e][h][0]);
+        acc[e][h][1] = mad_wide(k0, x1, acc[e][h][1]);
+        acc[e][h][2] = mad_wide(k0, x2, acc[e][h][2]);
+        acc[e][h][3] = mad_wide(k1, x0, acc[e][h][3]);
+        acc[e][h][4] = mad_wide(k1, x1, acc[e][h][4]);
+        acc[e][h][5] = mad_wide(k1, x2, acc[e][h][5]);
+      }
+    }
+  };
+  // the row pass of one digit (TWO = false) or of two digits side by side (second row image at + ROW4_LDS)
+  auto row_pass = [&](u64 (&xa)[4], u64 (&xb)[4], auto two_tag) {
+    constexpr bool TWO = decltype(two_tag)::value;
+#ifdef FHE_HIP_DEBUG
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { DBG_RANGE(xa[k], 2 * P.twop, 11); if constexpr (TWO) DBG_RANGE(xb[k], 2 * P.twop, 11); }
+#endif
+    fwd_phase_w<SP, 2>(xa, wA, P);                          // spans 128, 64: {t + 64k}
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pA[72 * k] = xa[k];
+    if constexpr (TWO) {
+      fwd_phase_w<SP, 2>(xb, wA, P);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pA[ROW4_LDS + 72 * k] = xb[k];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xa[k] = pB[18 * k];
+    if constexpr (TWO) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xb[k] = pB[ROW4_LDS + 18 * k];
+    }
+    wave_lds_sync();  // (all reads issued before the first write below: same wave, LDS operations complete in order)
+    fwd_phase_w<SP, 2>(xa, wB, P);                          // spans 32, 16
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pB[18 * k] = xa[k];
+    if constexpr (TWO) {
+      fwd_phase_w<SP, 2>(xb, wB, P);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pB[ROW4_LDS + 18 * k] = xb[k];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xa[k] = pC[4 * k];
+    if constexpr (TWO) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xb[k] = pC[ROW4_LDS + 4 * k];
+    }
+    wave_lds_sync();
+    fwd_phase_w<SP, 2>(xa, wC, P);                          // spans 8, 4
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pC[4 * k] = xa[k];
+    if constexpr (TWO) {
+      fwd_phase_w<SP, 2>(xb, wC, P);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pC[ROW4_LDS + 4 * k] = xb[k];
+    }
+    wave_lds_sync();
+    {
+      const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(pD), v1 = *reinterpret_cast<const ulonglong2 *>(pD + 2);
+      xa[0] = v0.x; xa[1] = v0.y; xa[2] = v1.x; xa[3] = v1.y;
+      if constexpr (TWO) {
+        const ulonglong2 w0 = *reinterpret_cast<const ulonglong2 *>(pD + ROW4_LDS), w1 = *reinterpret_cast<const ulonglong2 *>(pD + ROW4_LDS + 2);
+        xb[0] = w0.x; xb[1] = w0.y; xb[2] = w1.x; xb[3] = w1.y;
+      }
+    }
+    wave_lds_sync();  // the row images are rewritten by the next digits' first exchange
+    fwd_phase_w<SP, 2>(xa, wD, P);                          // spans 2, 1: {4t + k}, lazy in [0, 4p)
+    if constexpr (TWO) fwd_phase_w<SP, 2>(xb, wD, P);
+  };
+  // the digits other than the diagonal one, in order: q -> q (q < i) or q + 1
+  const bool has_diag = i < nd;
+  const u32 nnd = has_diag ? nd - 1 : nd;
+  auto dig = [&](u32 q) { const u32 qq = q < nnd ? q : nnd - 1; return (has_diag && qq >= i) ? qq + 1 : qq; };  // clamped: the tail re-requests the last digit
+  u64 xa[4], xb[4], na[4], nb_[4];
+  if (nnd) { load_digit(xa, dig(0)); load_digit(xb, dig(1)); }
+  if (has_diag) {  // digit j == i is ct[2] limb i itself (NTT_i(INTT_i(.)) = identity): no row pass, taken as the row pass would leave it
+    const u64 *s = a.diag + (u64)b * a.diag_bstride + (u64)i * N + row_off;   // wave-uniform base
+    const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(&s[4 * t]), v1 = *reinterpret_cast<const ulonglong2 *>(&s[4 * t + 2]);
+    const u64 xd[4] = {v0.x, v0.y, v1.x, v1.y};
+    const Keys kd = load_keys(i);
+    mac(xd, kd);
+  }
+  u32 q = 0;
+  for (; q + 1 < nnd; q += 2) {
+    // this pair's key words and the next pair's digits: requested before the row passes, which cover them
+    const Keys ka_ = load_keys(dig(q)), kb_ = load_keys(dig(q + 1));
+    load_digit(na, dig(q + 2));
+    load_digit(nb_, dig(q + 3));
+    row_pass(xa, xb, std::true_type{});
+    mac(xa, ka_);
+    mac(xb, kb_);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { xa[k] = na[k]; xb[k] = nb_[k]; }
+  }
+  if (q < nnd) {  // odd count: the last digit alone
+    const Keys ka_ = load_keys(dig(q));
+    row_pass(xa, xb, std::false_type{});
+    mac(xa, ka_);
+  }
+  const u64 half = (u64)a.nout * N;
+  u64 *o = a.out + ((u64)b * 2 * a.nout + i) * N + row_off + 4 * t;
+  u64 r[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[h][e] = relin_fold<SP>(acc[e][h], P);
+  const u64 *c0 = a.add0 ? a.add0 + (u64)b * a.add_bstride + (u64)i * N + row_off + 4 * t : nullptr;
+  const u64 *c1 = a.add1 ? a.add1 + (u64)b * a.add_bstride + (u64)i * N + row_off + 4 * t : nullptr;
+  if (c0) {
+    const ulonglong2 d0 = *reinterpret_cast<const ulonglong2 *>(c0), d1 = *reinterpret_cast<const ulonglong2 *>(c0 + 2);
+    r[0][0] = csub(r[0][0] + d0.x, P.p); r[0][1] = csub(r[0][1] + d0.y, P.p); r[0][2] = csub(r[0][2] + d1.x, P.p); r[0][3] = csub(r[0][3] + d1.y, P.p);
+  }
+  if (c1) {
+    const ulonglong2 d0 = *reinterpret_cast<const ulonglong2 *>(c1), d1 = *reinterpret_cast<const ulonglong2 *>(c1 + 2);
+    r[1][0] = csub(r[1][0] + d0.x, P.p); r[1][1] = csub(r[1][1] + d0.y, P.p); r[1][2] = csub(r[1][2] + d1.x, P.p); r[1][3] = csub(r[1][3] + d1.y, P.p);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) DBG_RANGE(r[h][e], P.p, 10);
+    *reinterpret_cast<ulonglong2 *>(o + h * half) = make_ulonglong2(r[h][0], r[h][1]);
+    *reinterpret_cast<ulonglong2 *>(o + h * half + 2) = make_ulonglong2(r[h][2], r[h][3]);
   }
 }
 

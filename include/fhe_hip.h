@@ -203,6 +203,9 @@ int fhe_hip_decode(fhe_hip_ctx *ctx, double *slots, const uint64_t *msg, uint32_
 #define FHE_HIP_TUNE_NTT_STREAMS 4 /* 2 (default): fhe_hip_ntt_forward / _backward at N >= 2^15 with at least two chunks of limbs (chunk =
                                     * FHE_HIP_TUNE_NTT_CHUNK, default 128) issue the chunks alternately on two library-owned streams forked from
                                     * and joined to the context's stream, so one chunk's column pass overlaps another's row pass; 1: one stream */
+#define FHE_HIP_TUNE_RELIN_KERNEL 5 /* 1 (default): digit key switch (relinearisation, MixedRotKey rotation) with unreduced key-MAC accumulators;
+                                    * 0: the Montgomery-MAC kernel of rounds 1-2 (A/B).  Set BEFORE loading the keys it applies to: the two kernels
+                                    * keep the key copies in different forms, and a key loaded for the other one is refused (FHE_HIP_ERR_NOKEY). */
 #define FHE_HIP_TUNE_ONEPASS 3     /* 1 (default): plain NTTs at N = 2^12 .. 2^14 run as one kernel with the limb in LDS; 0: pass pair */
 int fhe_hip_set_tuning(fhe_hip_ctx *ctx, int knob, uint64_t value);
 
