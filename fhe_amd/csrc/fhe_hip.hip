@@ -4,6 +4,7 @@
 #include "../../include/fhe_hip.h"
 #include "ntt_kernels.h"
 #include "pointwise_kernels.h"
+#include "bconv_mfma_kernels.h"
 #include "encoder_kernels.h"
 
 #include <cstdio>
@@ -69,6 +70,12 @@ struct fhe_hip_ctx {
   u64 *d_hat_qj_inv_m = nullptr;                 // [L-1][L]     mod q_j
   u64 *d_hat_qj_pi_m = nullptr;                  // [L-1][K][L]  mod p_k, times 2^128
   u64 *d_qinv_m = nullptr;                       // [M][M]: (P[a]^-1 mod P[j]) Montgomery, row a
+  // base conversion on the matrix cores (bconv_mfma_kernels.h): per-prime bias constant, and the Toeplitz byte images of the
+  // conversion tables, built on first use (key: 0 = special -> normal, Li = normal limbs 0..Li-1 -> special)
+  u64 *d_bconv_bias = nullptr;                   // [M]  2^22 (2^128 - 1)/255 * 2^-128 mod p_m
+  std::map<u32, uint4 *> bconv_tables;
+  uint32_t bconv_mode = 0;                       // FHE_HIP_TUNE_BCONV: 0 = by shape and size, 1 = vector-ALU kernel only, 2 = MFMA kernel whenever the shape allows
+  bool bconv_attr_set = false;
   // encoder (fhe_hip_encode / _decode), built on first use: psi^brv(i) as complex doubles, the generator-3 slot index map, and the
   // Garner constants of the CRT lift over the normal primes
   cplx *d_enc_roots = nullptr; u32 *d_enc_map = nullptr;
@@ -411,6 +418,68 @@ int check_ctx(fhe_hip_ctx *c) {
 
 // ---- device pipelines (all pointers device) ------------------------------------------------------
 
+// Base conversion with ready-made digits on the matrix cores (bconv_mfma_kernels.h) when the shape allows and the launch is
+// large enough to fill persistent workgroups; returns false when the vector-ALU kernel has to run instead.
+template <int NS>
+int launch_bconv_mfma(fhe_hip_ctx *c, const char *name, const BconvMfmaArgs &m, unsigned grid, size_t smem) {
+  if (!c->bconv_attr_set) {   // the table takes more LDS than the default dynamic limit
+    HIPCHK(c, hipFuncSetAttribute((const void *)bconv_mfma_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void *)bconv_mfma_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void *)bconv_mfma_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void *)bconv_mfma_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void *)bconv_mfma_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void *)bconv_mfma_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void *)bconv_mfma_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(c, hipFuncSetAttribute((const void *)bconv_mfma_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    c->bconv_attr_set = true;
+  }
+  hipEvent_t ev0 = nullptr;
+  if (c->prof && !c->fixed_ws) ev0 = c->chain_valid ? c->chain_ev : prof_event(c);
+  if (c->sp) hipLaunchKernelGGL((bconv_mfma_kernel<true, NS>), dim3(grid), dim3(BCONV_MFMA_THREADS), smem, c->stream, m);
+  else hipLaunchKernelGGL((bconv_mfma_kernel<false, NS>), dim3(grid), dim3(BCONV_MFMA_THREADS), smem, c->stream, m);
+  if (c->prof && !c->fixed_ws) {
+    c->chain_ev = prof_event(c); c->chain_valid = true;
+    prof_entry(c, name)->pending.push_back({ev0, c->chain_ev});
+  }
+  HIPCHK(c, hipGetLastError());
+  return FHE_HIP_OK;
+}
+int try_bconv_mfma(fhe_hip_ctx *c, const char *name, const BconvArgs &a, u32 table_key, u32 table_ntgt, u32 batch, bool *done) {
+  *done = false;
+  if (c->bconv_mode == 1 || c->fixed_ws || a.nsrc > 32 || a.ntgt == 0 || c->N < BCONV_MFMA_BLOCK) return FHE_HIP_OK;
+  const u32 NS = (a.nsrc + 7) / 8, ngroups = (a.ntgt + 3) / 4;
+  const size_t smem = (size_t)ngroups * 4 * NS * 64 * 16;
+  if (smem > 156 * 1024) return FHE_HIP_OK;
+  const u32 bpe = (u32)(c->N / BCONV_MFMA_BLOCK), nblocks = bpe * batch;
+  if (c->bconv_mode == 0 && nblocks < 2 * (u32)c->num_cus) return FHE_HIP_OK;   // too small to pay for the per-workgroup table load
+  uint4 *table = nullptr;
+  auto it = c->bconv_tables.find(table_key);
+  if (it != c->bconv_tables.end()) table = it->second;
+  else {
+    // all table_ntgt targets of the conversion (a launch for fewer targets reads a prefix: the image is grouped by target)
+    const u32 tgroups = (table_ntgt + 3) / 4, nfrag = tgroups * 4 * NS * 64;
+    HIPCHK(c, hipMalloc((void **)&table, (size_t)nfrag * 16));
+    c->bconv_tables[table_key] = table;
+    HIPCHK(c, prof_chain_break(c));
+    hipLaunchKernelGGL(bconv_table_kernel, dim3((nfrag + 255) / 256), dim3(256), 0, c->stream, table, a.hat_m, a.hat_stride, a.nsrc, table_ntgt, NS, tgroups);
+    HIPCHK(c, hipGetLastError());
+  }
+  BconvMfmaArgs m;
+  m.out = a.out; m.src = a.src; m.table = table; m.primes = a.primes; m.bias = c->d_bconv_bias;
+  m.nsrc = a.nsrc; m.src_limbs = a.src_limbs; m.src_off = a.src_off;
+  m.tgt_first = a.tgt_first; m.out_limbs = a.out_limbs; m.out_off = a.out_off; m.ntgt = a.ntgt; m.ngroups = ngroups;
+  m.nblocks = nblocks; m.blocks_per_entry = bpe; m.N = c->N;
+  const unsigned grid = nblocks < (u32)c->num_cus ? nblocks : (unsigned)c->num_cus;
+  switch (NS) {
+    case 1: TRY(launch_bconv_mfma<1>(c, name, m, grid, smem)); break;
+    case 2: TRY(launch_bconv_mfma<2>(c, name, m, grid, smem)); break;
+    case 3: TRY(launch_bconv_mfma<3>(c, name, m, grid, smem)); break;
+    default: TRY(launch_bconv_mfma<4>(c, name, m, grid, smem)); break;
+  }
+  *done = true;
+  return FHE_HIP_OK;
+}
+
 // BaseConverter::approximated_mod_up body on device: special limbs of rop from power-basis op
 int dev_conv_to_special(fhe_hip_ctx *c, u64 *rop, u32 rop_limbs, u32 rop_off, const u64 *op, u32 op_limbs, u32 Li, u32 batch, bool pre_scaled = false) {
   if (c->K == 0 || batch == 0) return FHE_HIP_OK;  // nothing to convert to
@@ -424,6 +493,7 @@ int dev_conv_to_special(fhe_hip_ctx *c, u64 *rop, u32 rop_limbs, u32 rop_off, co
   a.N = c->N;
   const dim3 grid((unsigned)(c->N / PW_THREADS), (c->K + BCONV_TC - 1) / BCONV_TC, batch);
   // pre_scaled: op already holds the digits [x_k * inv_k]_{q_k} (the producing inverse NTT was scaled by N^-1 * inv_k)
+  if (pre_scaled) { bool done; TRY(try_bconv_mfma(c, "bconv_modup", a, Li, c->K, batch, &done)); if (done) return FHE_HIP_OK; }
   if (pre_scaled) { if (c->sp) LAUNCH(c, "bconv_modup", (bconv_kernel<true, true>), grid, dim3(PW_THREADS), a); else LAUNCH(c, "bconv_modup", (bconv_kernel<false, true>), grid, dim3(PW_THREADS), a); }
   else { if (c->sp) LAUNCH(c, "bconv_modup", (bconv_kernel<true, false>), grid, dim3(PW_THREADS), a); else LAUNCH(c, "bconv_modup", (bconv_kernel<false, false>), grid, dim3(PW_THREADS), a); }
   return FHE_HIP_OK;
@@ -454,6 +524,8 @@ int dev_conv_to_normal(fhe_hip_ctx *c, u64 *rop, u32 L0, const u64 *op, u32 op_l
   a.tgt_first = 0; a.out_limbs = L0; a.out_off = 0; a.hat_stride = c->K; a.ntgt = L0;
   a.N = c->N;
   const dim3 grid((unsigned)(c->N / PW_THREADS), (L0 + BCONV_TC - 1) / BCONV_TC, batch);
+  // (the table of the special -> normal conversion does not depend on L0: a launch for fewer targets uses its first groups)
+  if (pre_scaled) { bool done; TRY(try_bconv_mfma(c, "bconv_moddown", a, 0, c->L, batch, &done)); if (done) return FHE_HIP_OK; }
   if (pre_scaled) { if (c->sp) LAUNCH(c, "bconv_moddown", (bconv_kernel<true, true>), grid, dim3(PW_THREADS), a); else LAUNCH(c, "bconv_moddown", (bconv_kernel<false, true>), grid, dim3(PW_THREADS), a); }
   else { if (c->sp) LAUNCH(c, "bconv_moddown", (bconv_kernel<true, false>), grid, dim3(PW_THREADS), a); else LAUNCH(c, "bconv_moddown", (bconv_kernel<false, false>), grid, dim3(PW_THREADS), a); }
   return FHE_HIP_OK;
@@ -853,6 +925,18 @@ int fhe_hip_ctx_create(fhe_hip_ctx **out, uint32_t logN, uint32_t L, uint32_t K,
   if ((rc = upload(c, &c->d_hat_pi_inv_m, hat_pi_inv)) || (rc = upload(c, &c->d_neg_hat_pi_qj_m, neg_hat)) || (rc = upload(c, &c->d_Pinv_qj_m, Pinv)) ||
       (rc = upload(c, &c->d_hat_qj_inv_m, hat_qj_inv)) || (rc = upload(c, &c->d_hat_qj_pi_m, hat_qj_pi)) || (rc = upload(c, &c->d_qinv_m, qinv)))
     return fail(rc);
+  {
+    // bconv_mfma_kernel's accumulators start at 2^22: sixteen byte weights carry Bias = 2^22 (2^128 - 1)/255 into the sum
+    std::vector<u64> bias(M);
+    for (uint32_t m = 0; m < M; ++m) {
+      const u64 p = primes[m];
+      u64 b = 0;
+      for (int s = 0; s < 16; ++s) b = (b + h_powmod(2, 22 + 8 * s, p)) % p;
+      const u64 r128 = h_powmod(2, 128, p);
+      bias[m] = h_mulmod(b, h_invmod(r128, p), p);
+    }
+    if ((rc = upload(c, &c->d_bconv_bias, bias))) return fail(rc);
+  }
   *out = c;
   return FHE_HIP_OK;
   } catch (...) { return abi_exception(); }
@@ -864,8 +948,9 @@ void fhe_hip_ctx_destroy(fhe_hip_ctx *c) {
   hipDeviceSynchronize();
   prof_drain(c);
   void *ptrs[] = {c->d_primes, c->d_tw_fwd, c->d_tw_inv, c->d_iota, c->d_rotmap, c->d_hat_pi_inv_m, c->d_neg_hat_pi_qj_m, c->d_Pinv_qj_m,
-                  c->d_hat_qj_inv_m, c->d_hat_qj_pi_m, c->d_qinv_m, c->d_mk_beta, c->d_mk_alpha, c->d_modup_scale_m, c->d_moddown_scale_m};
+                  c->d_hat_qj_inv_m, c->d_hat_qj_pi_m, c->d_qinv_m, c->d_mk_beta, c->d_mk_alpha, c->d_modup_scale_m, c->d_moddown_scale_m, c->d_bconv_bias};
   for (void *p : ptrs) if (p) hipFree(p);
+  for (auto &kv : c->bconv_tables) hipFree(kv.second);
   for (auto &kv : c->rot_keys) { hipFree(kv.second.beta_m); hipFree(kv.second.alpha_m); }
   for (auto &kv : c->mixed_keys) { hipFree(kv.second.beta_m); hipFree(kv.second.alpha_m); }
   for (auto &kv : c->galois_perm) hipFree(kv.second);
@@ -1305,6 +1390,7 @@ int fhe_hip_set_tuning(fhe_hip_ctx *c, int knob, uint64_t value) {
   if (knob == FHE_HIP_TUNE_ONEPASS) { c->onepass = value ? 1u : 0u; return FHE_HIP_OK; }
   if (knob == FHE_HIP_TUNE_NTT_CHUNK) { c->ntt_chunk = value > 32768 ? 32768u : (uint32_t)value; return FHE_HIP_OK; }
   if (knob == FHE_HIP_TUNE_RELIN_KERNEL) { c->relin4 = value ? 1u : 0u; return FHE_HIP_OK; }
+  if (knob == FHE_HIP_TUNE_BCONV) { if (value > 2) FAIL(c, FHE_HIP_ERR_RANGE, "FHE_HIP_TUNE_BCONV takes 0, 1 or 2"); c->bconv_mode = value; return FHE_HIP_OK; }
   if (knob == FHE_HIP_TUNE_NTT_STREAMS) { c->ntt_streams = value >= 2 ? 2u : 1u; return FHE_HIP_OK; }
   FAIL(c, FHE_HIP_ERR_ARG, "unknown tuning knob");
 }

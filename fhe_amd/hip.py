@@ -119,6 +119,7 @@ TUNE_NTT_CHUNK = 2
 TUNE_ONEPASS = 3
 TUNE_NTT_STREAMS = 4
 TUNE_RELIN_KERNEL = 5
+TUNE_BCONV = 6
 NOALLOC_SCRATCH_BYTES = 256 << 20
 
 

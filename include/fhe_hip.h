@@ -206,6 +206,10 @@ int fhe_hip_decode(fhe_hip_ctx *ctx, double *slots, const uint64_t *msg, uint32_
 #define FHE_HIP_TUNE_RELIN_KERNEL 5 /* 1 (default): digit key switch (relinearisation, MixedRotKey rotation) with unreduced key-MAC accumulators;
                                     * 0: the Montgomery-MAC kernel of rounds 1-2 (A/B).  Set BEFORE loading the keys it applies to: the two kernels
                                     * keep the key copies in different forms, and a key loaded for the other one is refused (FHE_HIP_ERR_NOKEY). */
+#define FHE_HIP_TUNE_BCONV 6        /* base conversions whose digits arrive ready-made (the rotation pipelines).  0 (default): on the matrix cores
+                                    * (byte-decomposed integer product on v_mfma_i32_16x16x64_i8) when the conversion has <= 32 source limbs, its
+                                    * byte image fits one CU's LDS and the launch fills persistent workgroups, else on the vector ALU;
+                                    * 1: vector-ALU kernel only; 2: matrix cores whenever the shape allows.  Identical results. */
 #define FHE_HIP_TUNE_ONEPASS 3     /* 1 (default): plain NTTs at N = 2^12 .. 2^14 run as one kernel with the limb in LDS; 0: pass pair */
 int fhe_hip_set_tuning(fhe_hip_ctx *ctx, int knob, uint64_t value);
 

@@ -448,6 +448,40 @@ def test_rotate_keyswitch(logN, L, K, Li, sp):
         g.rotate(7, d, Li, batch=B)  # no key loaded for this galois element
 
 
+@pytest.mark.parametrize("logN,L,K,Li,sp", [(10, 4, 4, 4, True), (10, 5, 3, 2, True), (11, 3, 2, 3, False), (10, 17, 17, 17, True),
+                                            (10, 17, 9, 12, False), (12, 9, 10, 9, True), (10, 30, 30, 30, True), (10, 31, 29, 27, False)])
+def test_base_conversion_on_the_matrix_cores_matches_the_vector_alu_kernel_and_the_oracle(logN, L, K, Li, sp):
+    """The rotation pipelines' base conversions (base_converter.cpp:313-349) as a byte-decomposed integer product on
+    v_mfma_i32_16x16x64_i8 (bconv_mfma_kernels.h), forced at shapes where the default would pick the vector-ALU kernel: 1..4 k-steps
+    (<= 8, 16, 24, 32 source limbs), target counts that are not multiples of four, a conversion to fewer normal limbs than the
+    table holds (Li < L), both prime kinds; bit-exact against the oracle and against the vector-ALU kernel."""
+    o, g = ctx_pair(logN, L, K, sp)
+    sx, ext = o.keygen_sk(seed=490)
+    gal = o.rotation_galois(1)
+    rkb, rka = o.keygen_rot(sx, ext, gal, seed=491)
+    g.load_rot_key(gal, dev(rkb), dev(rka))
+    B = 3
+    ct = np.stack([np.stack([rand_poly(o, range(Li), 500 + 2 * b), rand_poly(o, range(Li), 501 + 2 * b)]) for b in range(B)])
+    want = np.stack([np.stack(o.rotate(ct[b, 0], ct[b, 1], gal, rkb, rka)) for b in range(B)])
+    want_nn = np.stack([np.stack(o.rotate_non_ntt(ct[b, 0], ct[b, 1], gal, rkb, rka)) for b in range(B)])
+    got = {}
+    try:
+        for mode in (2, 1):
+            g.set_tuning(fhe_amd.hip.TUNE_BCONV, mode)
+            d = dev(ct)
+            g.rotate(gal, d, Li, batch=B)
+            got[mode] = host(d)
+            assert np.array_equal(got[mode], want), mode
+            d = dev(ct)
+            g.rotate_non_ntt(gal, d, Li, batch=B)
+            assert np.array_equal(host(d), want_nn), mode
+        with pytest.raises(fhe_amd.FheHipError):
+            g.set_tuning(fhe_amd.hip.TUNE_BCONV, 3)
+    finally:
+        g.set_tuning(fhe_amd.hip.TUNE_BCONV, 0)
+    assert np.array_equal(got[1], got[2])
+
+
 @pytest.mark.parametrize("logN,L,K,Li,sp", [(10, 4, 4, 4, True), (10, 4, 2, 2, True), (11, 3, 2, 3, False), (12, 9, 3, 9, True)])
 def test_rotate_non_ntt_keyswitch(logN, L, K, Li, sp):
     """power-basis rotation (evaluator.cpp:327-339, 520-574), the reference's arithmetic taken literally."""
