@@ -18,16 +18,19 @@
 //   row     = 4 g + r  <->  (target 4 grp + g, byte weight s = 4 a + r), a = 0..3 numbering four tiles per group of four targets.
 // The A operand is the Toeplitz image of the hat bytes (hat_{k, s - i}, zero outside 0..7; built once per conversion table by
 // bconv_table_kernel, read from LDS).  After the four tiles of a group, lane (column c, g) holds all sixteen S_s of
-// (coefficient c, target 4 grp + g): no cross-lane step.  The accumulators start at 2^22, so every S is a non-negative 24-bit
-// number and T + Bias (Bias = 2^22 (2^128 - 1) / 255) is put together with 32-bit shifts-and-adds and one multiply-add per four sums,
-// taken through two 64-bit Montgomery reductions (the hat tables carry the factor 2^128) and corrected by Bias * 2^-128 mod p.
-// ~50 VALU instructions per (coefficient, target) instead of ~250; half of the MFMA rows x k-slots are structural zeros of the
-// Toeplitz image, which the otherwise idle unit absorbs.
+// (coefficient c, target 4 grp + g): no cross-lane step.  The accumulators start at 2^22 + (a byte of D), so every S is a
+// non-negative 24-bit number, where D = -2^22 (2^128 - 1)/255 mod p is chosen per target so that the whole offset is a multiple
+// of the target prime and never has to be taken out again.  T + offset is put together with 32-bit shift-adds, funnel shifts and
+// one carry chain (18 instructions), then taken through two 64-bit Montgomery reductions (the hat tables carry the factor 2^128).
+// ~45 VALU instructions per (coefficient, target) instead of ~250; half of the MFMA rows x k-slots are structural zeros of the
+// Toeplitz image.  MFMA and VALU work of one SIMD overlap only in part (tools/ubench/mfma_valu.hip: a wave of MFMAs leaves the
+// vector ALU ~40 % of its issue slots), so both counts matter.
 //
 // Used when the digits are ready-made (the rotation pipelines: the producing inverse NTT carries inv_k in its scaling) and the
 // conversion has at most 32 source limbs; everything else runs bconv_kernel.
 #pragma once
 #include "pointwise_kernels.h"
+#include <type_traits>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -35,11 +38,16 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #define BCONV_MFMA_BLOCK 512            // coefficients per workgroup iteration (64 per wave = four 16-column tiles)
 #define BCONV_MFMA_ACC0 (1 << 22)       // accumulator bias: |S_s| <= 2^22
 
+// per-prime constants of a conversion target (one 48-byte record, read by the lanes that fold for it)
+struct BconvTgt {
+  u64 p, pinv;
+  u32 init[8];   // 2^22 + byte r of D: accumulator start values of byte weights 0..7 (weights 8..15 start at 2^22)
+};
+
 struct BconvMfmaArgs {
   u64 *out; const u64 *src;
-  const uint4 *table;     // [ngroups][4][NS][64] A fragments (16 bytes per lane)
-  const PrimeC *primes;
-  const u64 *bias;        // [M]  Bias * 2^-128 mod p_m, canonical
+  const uint4 *table;     // [ngroups][2][NS][2][64] A fragments (16 bytes per lane) in the order the kernel consumes them: tile 2h + b at [h][st][b]
+  const BconvTgt *tgt;    // [M]
   u32 nsrc, src_limbs, src_off;
   u32 tgt_first, out_limbs, out_off, ntgt, ngroups;
   u32 nblocks, blocks_per_entry;
@@ -55,7 +63,7 @@ __device__ __forceinline__ u64 balanced_bytes(u64 v) {
 __global__ void bconv_table_kernel(uint4 *table, const u64 *hat_m, u32 hat_stride, u32 nsrc, u32 ntgt, u32 NS, u32 ngroups) {
   const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= ngroups * 4 * NS * 64) return;
-  const u32 lane = idx & 63, f = idx >> 6, st = f % NS, a4 = (f / NS) & 3, grp = f / NS / 4;
+  const u32 lane = idx & 63, f = idx >> 6, st = (f >> 1) % NS, hh = ((f >> 1) / NS) & 1, a4 = 2 * hh + (f & 1), grp = (f >> 1) / NS / 2;
   const u32 m = lane & 15, kg = lane >> 4;
   const u32 t = grp * 4 + (m >> 2);
   const int s = (int)(4 * a4 + (m & 3));
@@ -71,28 +79,40 @@ __global__ void bconv_table_kernel(uint4 *table, const u64 *hat_m, u32 hat_strid
   table[idx] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// sixteen biased byte-convolution sums (four accumulator tiles) of one (coefficient, target) -> the canonical residue
+// Fold of the sixteen offset byte-convolution sums of one (coefficient, target) into the canonical residue, in two halves
+// (tiles 0, 1, then tiles 2, 3).  Word a of the sum collects Z_a = S_4a + 2^8 S_4a+1 (one 32-bit shift-add: both
+// < 2^23 + 2^8) and, 16 bits up, Y_a = S_4a+2 + 2^8 S_4a+3, whose upper half spills into word a + 1: V_a = (Y_a : Y_a-1) >> 16 is one
+// funnel shift, and one carry chain adds Z and V.
+struct BconvFoldState { u64 r1; u32 y1, cy; };
+// tiles 0, 1 (byte weights 0..7): words 0, 1 and their Montgomery reduction X0 * 2^-64 mod p, in (0, p]
 template <bool SP>
-__device__ __forceinline__ u64 bconv_mfma_fold(const v4i &c0, const v4i &c1, const v4i &c2, const v4i &c3, const PrimeC &PT, u64 biasc) {
-  u32 w[5];
-  u32 carry = 0;
-  const v4i *cc[4] = {&c0, &c1, &c2, &c3};
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const u32 s0 = (u32)(*cc[a])[0], s1 = (u32)(*cc[a])[1], s2 = (u32)(*cc[a])[2], s3 = (u32)(*cc[a])[3];
-    const u32 z = (s1 << 8) + s0 + carry;   // < 2^31 + 2^23 + 2^17
-    const u32 y = (s3 << 8) + s2;
-    const u64 X = mad_wide(y, 65536u, (u64)z);
-    w[a] = (u32)X;
-    carry = (u32)(X >> 32);                 // < 2^17
-  }
-  w[4] = carry;
-  const u64 X0 = pair64(w[0], w[1]), X1 = pair64(w[2], w[3]);
-  const u64 r1 = mont_reduce<SP>(0, X0, PT);                  // X0 * 2^-64 (mod p), in (0, p]
-  const u64 w_lo = X1 + r1;
-  const u64 w_hi = (u64)w[4] + (w_lo < r1 ? 1u : 0u);
-  const u64 r = csub(mont_reduce<SP>(w_hi, w_lo, PT), PT.p);  // (T + Bias) * 2^-128 mod p, canonical
-  return r >= biasc ? r - biasc : r + PT.p - biasc;
+__device__ __forceinline__ BconvFoldState bconv_fold_start(const v4i &c0, const v4i &c1, u64 p, u64 pinv) {
+  const u32 z0 = ((u32)c0[1] << 8) + (u32)c0[0], y0 = ((u32)c0[3] << 8) + (u32)c0[2];
+  const u32 z1 = ((u32)c1[1] << 8) + (u32)c1[0], y1 = ((u32)c1[3] << 8) + (u32)c1[2];
+  u32 cy;
+  const u32 w0 = __builtin_addc(z0, y0 << 16, 0u, &cy);
+  const u32 w1 = __builtin_addc(z1, __builtin_amdgcn_alignbit(y1, y0, 16), cy, &cy);
+  PrimeC PT;
+  PT.p = p; PT.pinv = pinv; PT.p1 = (u32)(p >> 32);
+  BconvFoldState s;
+  s.r1 = mont_reduce<SP>(0, pair64(w0, w1), PT);
+  s.y1 = y1; s.cy = cy;
+  return s;
+}
+// tiles 2, 3 (byte weights 8..15): words 2..4, joined with the first half and reduced once more: (T + k p) * 2^-128 mod p, canonical
+template <bool SP>
+__device__ __forceinline__ u64 bconv_fold_finish(const v4i &c2, const v4i &c3, const BconvFoldState &s, u64 p, u64 pinv) {
+  const u32 z2 = ((u32)c2[1] << 8) + (u32)c2[0], y2 = ((u32)c2[3] << 8) + (u32)c2[2];
+  const u32 z3 = ((u32)c3[1] << 8) + (u32)c3[0], y3 = ((u32)c3[3] << 8) + (u32)c3[2];
+  u32 cy;
+  const u32 w2 = __builtin_addc(z2, __builtin_amdgcn_alignbit(y2, s.y1, 16), s.cy, &cy);
+  const u32 w3 = __builtin_addc(z3, __builtin_amdgcn_alignbit(y3, y2, 16), cy, &cy);
+  const u32 w4 = (y3 >> 16) + cy;
+  PrimeC PT;
+  PT.p = p; PT.pinv = pinv; PT.p1 = (u32)(p >> 32);
+  const u64 w_lo = pair64(w2, w3) + s.r1;
+  const u64 w_hi = (u64)w4 + (w_lo < s.r1 ? 1u : 0u);
+  return csub(mont_reduce<SP>(w_hi, w_lo, PT), p);
 }
 
 template <bool SP, int NS>
@@ -104,45 +124,106 @@ __global__ __launch_bounds__(BCONV_MFMA_THREADS) void bconv_mfma_kernel(BconvMfm
   for (u32 i = tid; i < nfrag; i += BCONV_MFMA_THREADS) tab[i] = a.table[i];
   __syncthreads();
   const u32 last = a.nsrc - 1;
+  // A fragments: one cyclic stream of phases (a group's tiles 0,1 over all k-steps, then its tiles 2,3), PH fragments per phase,
+  // held in a ring of R registers sets: the fragment R positions ahead is requested right after the multiply-adds of the current
+  // one were issued, so an LDS read has >= 16 MFMAs to arrive.  The stream wraps from the last group to the first.
+  constexpr int PH = 2 * NS, R = (PH % 4 == 0) ? 4 : PH;
+  const uint4 *tq = tab + lane;
+  const u32 nq = a.ngroups * 2 * PH * 64;   // table length in uint4
+  u32 qc = 0, qx = PH * 64 < nq ? PH * 64 : 0;   // offsets of the current and the next phase
+  uint4 fr[R];
+#pragma unroll
+  for (int n = 0; n < R; ++n) fr[n] = tq[n * 64];
+  // digits of the block as B operands: B[ct][st] = limbs 8 st + 2 g, + 1 of coefficient 16 ct + col.  They are requested for the
+  // NEXT block during the last group of the current one, k-step by k-step as the registers fall free, and arrive raw; each block
+  // starts by turning them into balanced bytes.
+  // (limbs beyond the source basis meet zero rows of the table: any valid address will do)
+  u64 koff[NS][2];
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    const u32 k0 = 8 * st + 2 * g, k1 = k0 + 1;
+    koff[st][0] = (u64)(k0 < last ? k0 : last) * a.N; koff[st][1] = (u64)(k1 < last ? k1 : last) * a.N;
+  }
+  auto block_src = [&](u32 blk) {
+    const u32 e = blk / a.blocks_per_entry;
+    return a.src + ((u64)e * a.src_limbs + a.src_off) * a.N + (u64)(blk % a.blocks_per_entry) * BCONV_MFMA_BLOCK + wave * 64 + col;
+  };
+  v4i B[4][NS];
+  auto request = [&](const u64 *sp, int st) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const u64 x0 = sp[koff[st][0] + 16 * ct], x1 = sp[koff[st][1] + 16 * ct];
+      B[ct][st] = v4i{(int)(u32)x0, (int)(u32)(x0 >> 32), (int)(u32)x1, (int)(u32)(x1 >> 32)};
+    }
+  };
+  if (blockIdx.x < a.nblocks) {
+    const u64 *sp = block_src(blockIdx.x);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) request(sp, st);
+  }
+  const v4i acc0 = v4i{BCONV_MFMA_ACC0, BCONV_MFMA_ACC0, BCONV_MFMA_ACC0, BCONV_MFMA_ACC0};
+  const BconvTgt *tp = a.tgt + a.tgt_first;
+  v4i acc[4][4];
+  // one half of a group's MFMAs (tiles 2 H, 2 H + 1 over all k-steps)
+  auto phase = [&](auto H, const v4i &c_lo, const v4i &c_hi, auto &&after_step) {
+    constexpr int h = decltype(H)::value;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int n = st * 2 + b;
+        const uint4 f = fr[n % R];
+        const v4i A = v4i{(int)f.x, (int)f.y, (int)f.z, (int)f.w};
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[2 * h + b][ct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B[ct][st], st == 0 ? (b == 0 ? c_lo : c_hi) : acc[2 * h + b][ct], 0, 0, 0);
+        const int m = n + R;
+        fr[n % R] = m < PH ? tq[qc + m * 64] : tq[qx + (m - PH) * 64];
+      }
+      after_step(st);
+      __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the LDS reads to just before their use)
+    }
+  };
+  auto advance = [&]() { qc = qx; qx = qx + PH * 64; qx = qx < nq ? qx : 0; };
+
   for (u32 blk = blockIdx.x; blk < a.nblocks; blk += gridDim.x) {   // bounded: every wave leaves after its last block
     const u32 e = blk / a.blocks_per_entry;
     const u64 d = (u64)(blk % a.blocks_per_entry) * BCONV_MFMA_BLOCK + wave * 64 + col;
-    const u64 *sp = a.src + ((u64)e * a.src_limbs + a.src_off) * a.N + d;
-    v4i B[4][NS];
+    const u32 nblk = blk + gridDim.x;
+    const u64 *spn = block_src(nblk < a.nblocks ? nblk : blk);   // (after the last block: a harmless re-read of this one)
 #pragma unroll
-    for (int st = 0; st < NS; ++st) {
-      const u32 k0 = 8 * st + 2 * g, k1 = k0 + 1;     // limbs beyond the source basis meet zero rows of the table: any valid address will do
-      const u64 *r0 = sp + (u64)(k0 < last ? k0 : last) * a.N, *r1 = sp + (u64)(k1 < last ? k1 : last) * a.N;
+    for (int st = 0; st < NS; ++st)
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
-        const u64 x0 = balanced_bytes(r0[16 * ct]), x1 = balanced_bytes(r1[16 * ct]);
+        const u64 x0 = balanced_bytes(pair64((u32)B[ct][st][0], (u32)B[ct][st][1])), x1 = balanced_bytes(pair64((u32)B[ct][st][2], (u32)B[ct][st][3]));
         B[ct][st] = v4i{(int)(u32)x0, (int)(u32)(x0 >> 32), (int)(u32)x1, (int)(u32)(x1 >> 32)};
       }
-    }
+    // target constants one group ahead (a global load waited for where it is used costs its whole latency per group)
+    u32 tcn = g < a.ntgt ? g : a.ntgt - 1;
+    u64 pn = tp[tcn].p, pinvn = tp[tcn].pinv;
+    v4i i0n = *reinterpret_cast<const v4i *>(tp[tcn].init), i1n = *reinterpret_cast<const v4i *>(tp[tcn].init + 4);
     for (u32 grp = 0; grp < a.ngroups; ++grp) {
-      v4i acc[4][4];
-#pragma unroll
-      for (int a4 = 0; a4 < 4; ++a4)
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[a4][ct] = v4i{BCONV_MFMA_ACC0, BCONV_MFMA_ACC0, BCONV_MFMA_ACC0, BCONV_MFMA_ACC0};
-      const uint4 *tg = tab + (u64)grp * 4 * NS * 64 + lane;
-#pragma unroll
-      for (int st = 0; st < NS; ++st)
-#pragma unroll
-        for (int a4 = 0; a4 < 4; ++a4) {
-          const uint4 f = tg[(a4 * NS + st) * 64];
-          const v4i A = v4i{(int)f.x, (int)f.y, (int)f.z, (int)f.w};
-#pragma unroll
-          for (int ct = 0; ct < 4; ++ct) acc[a4][ct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B[ct][st], acc[a4][ct], 0, 0, 0);
-        }
-      const u32 t = grp * 4 + g, tc = t < a.ntgt ? t : a.ntgt - 1;
-      const PrimeC PT = a.primes[a.tgt_first + tc];
-      const u64 biasc = a.bias[a.tgt_first + tc];
+      const u32 t = grp * 4 + g, tc = tcn;
+      const u64 p = pn, pinv = pinvn;
+      const v4i i0 = i0n, i1 = i1n;
+      {
+        const u32 t2 = t + 4;
+        tcn = t2 < a.ntgt ? t2 : a.ntgt - 1;
+        pn = tp[tcn].p; pinvn = tp[tcn].pinv;
+        i0n = *reinterpret_cast<const v4i *>(tp[tcn].init); i1n = *reinterpret_cast<const v4i *>(tp[tcn].init + 4);
+      }
+      phase(std::integral_constant<int, 0>(), i0, i1, [&](int) {});
+      advance();
+      // the next block's digits are requested during the last group, k-step by k-step as the registers fall free
+      if (grp + 1 == a.ngroups) phase(std::integral_constant<int, 1>(), acc0, acc0, [&](int st) { request(spn, st); });
+      else phase(std::integral_constant<int, 1>(), acc0, acc0, [&](int) {});
+      advance();
       u64 *op = a.out + ((u64)e * a.out_limbs + a.out_off + tc) * a.N + d;
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
-        const u64 r = bconv_mfma_fold<SP>(acc[0][ct], acc[1][ct], acc[2][ct], acc[3][ct], PT, biasc);
-        DBG_RANGE(r, PT.p, 13);
+        const BconvFoldState fs = bconv_fold_start<SP>(acc[0][ct], acc[1][ct], p, pinv);
+        const u64 r = bconv_fold_finish<SP>(acc[2][ct], acc[3][ct], fs, p, pinv);
+        DBG_RANGE(r, p, 13);
         if (t < a.ntgt) op[16 * ct] = r;
       }
     }

@@ -72,7 +72,7 @@ struct fhe_hip_ctx {
   u64 *d_qinv_m = nullptr;                       // [M][M]: (P[a]^-1 mod P[j]) Montgomery, row a
   // base conversion on the matrix cores (bconv_mfma_kernels.h): per-prime bias constant, and the Toeplitz byte images of the
   // conversion tables, built on first use (key: 0 = special -> normal, Li = normal limbs 0..Li-1 -> special)
-  u64 *d_bconv_bias = nullptr;                   // [M]  2^22 (2^128 - 1)/255 * 2^-128 mod p_m
+  BconvTgt *d_bconv_tgt = nullptr;               // [M]  per-prime constants of a conversion target (accumulator start values)
   std::map<u32, uint4 *> bconv_tables;
   uint32_t bconv_mode = 0;                       // FHE_HIP_TUNE_BCONV: 0 = by shape and size, 1 = vector-ALU kernel only, 2 = MFMA kernel whenever the shape allows
   bool bconv_attr_set = false;
@@ -465,7 +465,7 @@ int try_bconv_mfma(fhe_hip_ctx *c, const char *name, const BconvArgs &a, u32 tab
     HIPCHK(c, hipGetLastError());
   }
   BconvMfmaArgs m;
-  m.out = a.out; m.src = a.src; m.table = table; m.primes = a.primes; m.bias = c->d_bconv_bias;
+  m.out = a.out; m.src = a.src; m.table = table; m.tgt = c->d_bconv_tgt;
   m.nsrc = a.nsrc; m.src_limbs = a.src_limbs; m.src_off = a.src_off;
   m.tgt_first = a.tgt_first; m.out_limbs = a.out_limbs; m.out_off = a.out_off; m.ntgt = a.ntgt; m.ngroups = ngroups;
   m.nblocks = nblocks; m.blocks_per_entry = bpe; m.N = c->N;
@@ -926,16 +926,18 @@ int fhe_hip_ctx_create(fhe_hip_ctx **out, uint32_t logN, uint32_t L, uint32_t K,
       (rc = upload(c, &c->d_hat_qj_inv_m, hat_qj_inv)) || (rc = upload(c, &c->d_hat_qj_pi_m, hat_qj_pi)) || (rc = upload(c, &c->d_qinv_m, qinv)))
     return fail(rc);
   {
-    // bconv_mfma_kernel's accumulators start at 2^22: sixteen byte weights carry Bias = 2^22 (2^128 - 1)/255 into the sum
-    std::vector<u64> bias(M);
+    // bconv_mfma_kernel's accumulators start at 2^22 + a byte of D, D = -2^22 (2^128 - 1)/255 mod p: the sixteen byte weights
+    // then carry a multiple of p into the sum
+    std::vector<BconvTgt> tg(M);
     for (uint32_t m = 0; m < M; ++m) {
       const u64 p = primes[m];
       u64 b = 0;
       for (int s = 0; s < 16; ++s) b = (b + h_powmod(2, 22 + 8 * s, p)) % p;
-      const u64 r128 = h_powmod(2, 128, p);
-      bias[m] = h_mulmod(b, h_invmod(r128, p), p);
+      const u64 D = (p - b) % p;
+      tg[m].p = p; tg[m].pinv = pc[m].pinv;
+      for (int r = 0; r < 8; ++r) tg[m].init[r] = (1u << 22) + (u32)((D >> (8 * r)) & 0xFF);
     }
-    if ((rc = upload(c, &c->d_bconv_bias, bias))) return fail(rc);
+    if ((rc = upload(c, &c->d_bconv_tgt, tg))) return fail(rc);
   }
   *out = c;
   return FHE_HIP_OK;
@@ -948,7 +950,7 @@ void fhe_hip_ctx_destroy(fhe_hip_ctx *c) {
   hipDeviceSynchronize();
   prof_drain(c);
   void *ptrs[] = {c->d_primes, c->d_tw_fwd, c->d_tw_inv, c->d_iota, c->d_rotmap, c->d_hat_pi_inv_m, c->d_neg_hat_pi_qj_m, c->d_Pinv_qj_m,
-                  c->d_hat_qj_inv_m, c->d_hat_qj_pi_m, c->d_qinv_m, c->d_mk_beta, c->d_mk_alpha, c->d_modup_scale_m, c->d_moddown_scale_m, c->d_bconv_bias};
+                  c->d_hat_qj_inv_m, c->d_hat_qj_pi_m, c->d_qinv_m, c->d_mk_beta, c->d_mk_alpha, c->d_modup_scale_m, c->d_moddown_scale_m, c->d_bconv_tgt};
   for (void *p : ptrs) if (p) hipFree(p);
   for (auto &kv : c->bconv_tables) hipFree(kv.second);
   for (auto &kv : c->rot_keys) { hipFree(kv.second.beta_m); hipFree(kv.second.alpha_m); }
