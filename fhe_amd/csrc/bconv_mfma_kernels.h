@@ -26,8 +26,9 @@
 // Toeplitz image.  MFMA and VALU work of one SIMD overlap only in part (tools/ubench/mfma_valu.hip: a wave of MFMAs leaves the
 // vector ALU ~40 % of its issue slots), so both counts matter.
 //
-// Used when the digits are ready-made (the rotation pipelines: the producing inverse NTT carries inv_k in its scaling) and the
-// conversion has at most 32 source limbs; everything else runs bconv_kernel.
+// Used when the conversion has at most 32 source limbs and the launch is large enough for persistent workgroups; everything
+// else runs bconv_kernel.  PRE: the digits arrive ready-made (the NTT-domain rotation pipeline: the producing inverse NTT carries
+// inv_k in its scaling); otherwise each lane forms the digits of the limbs it loads, [x_k * inv_k] mod src_k, once per block.
 #pragma once
 #include "pointwise_kernels.h"
 #include <type_traits>
@@ -48,6 +49,9 @@ struct BconvMfmaArgs {
   u64 *out; const u64 *src;
   const uint4 *table;     // [ngroups][2][NS][2][64] A fragments (16 bytes per lane) in the order the kernel consumes them: tile 2h + b at [h][st][b]
   const BconvTgt *tgt;    // [M]
+  const PrimeC *primes;   // [M]      (digits formed in the kernel: source primes src_first + k)
+  const u64 *inv_m;       // [nsrc]   (digits formed in the kernel) Montgomery form w.r.t. the source prime
+  u32 src_first;
   u32 nsrc, src_limbs, src_off;
   u32 tgt_first, out_limbs, out_off, ntgt, ngroups;
   u32 nblocks, blocks_per_entry;
@@ -115,7 +119,7 @@ __device__ __forceinline__ u64 bconv_fold_finish(const v4i &c2, const v4i &c3, c
   return csub(mont_reduce<SP>(w_hi, w_lo, PT), p);
 }
 
-template <bool SP, int NS>
+template <bool SP, int NS, bool PRE>
 __global__ __launch_bounds__(BCONV_MFMA_THREADS) void bconv_mfma_kernel(BconvMfmaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bconv_smem[];
   uint4 *tab = reinterpret_cast<uint4 *>(bconv_smem);
@@ -138,12 +142,23 @@ __global__ __launch_bounds__(BCONV_MFMA_THREADS) void bconv_mfma_kernel(BconvMfm
   // NEXT block during the last group of the current one, k-step by k-step as the registers fall free, and arrive raw; each block
   // starts by turning them into balanced bytes.
   // (limbs beyond the source basis meet zero rows of the table: any valid address will do)
-  u64 koff[NS][2];
+  u32 kidx[NS][2];
 #pragma unroll
   for (int st = 0; st < NS; ++st) {
     const u32 k0 = 8 * st + 2 * g, k1 = k0 + 1;
-    koff[st][0] = (u64)(k0 < last ? k0 : last) * a.N; koff[st][1] = (u64)(k1 < last ? k1 : last) * a.N;
+    kidx[st][0] = k0 < last ? k0 : last; kidx[st][1] = k1 < last ? k1 : last;
   }
+  // canonical digit [x * inv_k] mod src_k with lane-dependent constants (each lane owns its own limbs)
+  auto digit = [&](u64 x, u32 k) {
+    if constexpr (PRE) return x;
+    else {
+      const PrimeC &PS = a.primes[a.src_first + k];
+      PrimeC P;
+      P.p = PS.p; P.pinv = PS.pinv; P.p1 = (u32)(P.p >> 32); P.n32 = 0u - (u32)P.pinv; P.twop = 0; P.r2 = 0; P.ninv_m = 0;
+      const u64 D = mont_diff<SP>(a.inv_m[k], x, P);   // in (-p, p), mod 2^64
+      return (long long)D < 0 ? D + P.p : D;
+    }
+  };
   auto block_src = [&](u32 blk) {
     const u32 e = blk / a.blocks_per_entry;
     return a.src + ((u64)e * a.src_limbs + a.src_off) * a.N + (u64)(blk % a.blocks_per_entry) * BCONV_MFMA_BLOCK + wave * 64 + col;
@@ -152,7 +167,7 @@ __global__ __launch_bounds__(BCONV_MFMA_THREADS) void bconv_mfma_kernel(BconvMfm
   auto request = [&](const u64 *sp, int st) {
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
-      const u64 x0 = sp[koff[st][0] + 16 * ct], x1 = sp[koff[st][1] + 16 * ct];
+      const u64 x0 = sp[(u64)kidx[st][0] * a.N + 16 * ct], x1 = sp[(u64)kidx[st][1] * a.N + 16 * ct];
       B[ct][st] = v4i{(int)(u32)x0, (int)(u32)(x0 >> 32), (int)(u32)x1, (int)(u32)(x1 >> 32)};
     }
   };
@@ -195,7 +210,8 @@ __global__ __launch_bounds__(BCONV_MFMA_THREADS) void bconv_mfma_kernel(BconvMfm
     for (int st = 0; st < NS; ++st)
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
-        const u64 x0 = balanced_bytes(pair64((u32)B[ct][st][0], (u32)B[ct][st][1])), x1 = balanced_bytes(pair64((u32)B[ct][st][2], (u32)B[ct][st][3]));
+        const u64 x0 = balanced_bytes(digit(pair64((u32)B[ct][st][0], (u32)B[ct][st][1]), kidx[st][0]));
+        const u64 x1 = balanced_bytes(digit(pair64((u32)B[ct][st][2], (u32)B[ct][st][3]), kidx[st][1]));
         B[ct][st] = v4i{(int)(u32)x0, (int)(u32)(x0 >> 32), (int)(u32)x1, (int)(u32)(x1 >> 32)};
       }
     // target constants one group ahead (a global load waited for where it is used costs its whole latency per group)

@@ -75,7 +75,7 @@ struct fhe_hip_ctx {
   BconvTgt *d_bconv_tgt = nullptr;               // [M]  per-prime constants of a conversion target (accumulator start values)
   std::map<u32, uint4 *> bconv_tables;
   uint32_t bconv_mode = 0;                       // FHE_HIP_TUNE_BCONV: 0 = by shape and size, 1 = vector-ALU kernel only, 2 = MFMA kernel whenever the shape allows
-  bool bconv_attr_set = false;
+  bool bconv_attr_set[4][2] = {{false, false}, {false, false}, {false, false}, {false, false}};
   // encoder (fhe_hip_encode / _decode), built on first use: psi^brv(i) as complex doubles, the generator-3 slot index map, and the
   // Garner constants of the CRT lift over the normal primes
   cplx *d_enc_roots = nullptr; u32 *d_enc_map = nullptr;
@@ -420,23 +420,18 @@ int check_ctx(fhe_hip_ctx *c) {
 
 // Base conversion with ready-made digits on the matrix cores (bconv_mfma_kernels.h) when the shape allows and the launch is
 // large enough to fill persistent workgroups; returns false when the vector-ALU kernel has to run instead.
-template <int NS>
+template <int NS, bool PRE>
 int launch_bconv_mfma(fhe_hip_ctx *c, const char *name, const BconvMfmaArgs &m, unsigned grid, size_t smem) {
-  if (!c->bconv_attr_set) {   // the table takes more LDS than the default dynamic limit
-    HIPCHK(c, hipFuncSetAttribute((const void *)bconv_mfma_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(c, hipFuncSetAttribute((const void *)bconv_mfma_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(c, hipFuncSetAttribute((const void *)bconv_mfma_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(c, hipFuncSetAttribute((const void *)bconv_mfma_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(c, hipFuncSetAttribute((const void *)bconv_mfma_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(c, hipFuncSetAttribute((const void *)bconv_mfma_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(c, hipFuncSetAttribute((const void *)bconv_mfma_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(c, hipFuncSetAttribute((const void *)bconv_mfma_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    c->bconv_attr_set = true;
+  const void *fn = c->sp ? (const void *)bconv_mfma_kernel<true, NS, PRE> : (const void *)bconv_mfma_kernel<false, NS, PRE>;
+  bool &attr = c->bconv_attr_set[NS - 1][PRE ? 1 : 0];
+  if (!attr) {   // the table takes more LDS than the default dynamic limit
+    HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
   }
   hipEvent_t ev0 = nullptr;
   if (c->prof && !c->fixed_ws) ev0 = c->chain_valid ? c->chain_ev : prof_event(c);
-  if (c->sp) hipLaunchKernelGGL((bconv_mfma_kernel<true, NS>), dim3(grid), dim3(BCONV_MFMA_THREADS), smem, c->stream, m);
-  else hipLaunchKernelGGL((bconv_mfma_kernel<false, NS>), dim3(grid), dim3(BCONV_MFMA_THREADS), smem, c->stream, m);
+  if (c->sp) hipLaunchKernelGGL((bconv_mfma_kernel<true, NS, PRE>), dim3(grid), dim3(BCONV_MFMA_THREADS), smem, c->stream, m);
+  else hipLaunchKernelGGL((bconv_mfma_kernel<false, NS, PRE>), dim3(grid), dim3(BCONV_MFMA_THREADS), smem, c->stream, m);
   if (c->prof && !c->fixed_ws) {
     c->chain_ev = prof_event(c); c->chain_valid = true;
     prof_entry(c, name)->pending.push_back({ev0, c->chain_ev});
@@ -444,7 +439,7 @@ int launch_bconv_mfma(fhe_hip_ctx *c, const char *name, const BconvMfmaArgs &m, 
   HIPCHK(c, hipGetLastError());
   return FHE_HIP_OK;
 }
-int try_bconv_mfma(fhe_hip_ctx *c, const char *name, const BconvArgs &a, u32 table_key, u32 table_ntgt, u32 batch, bool *done) {
+int try_bconv_mfma(fhe_hip_ctx *c, const char *name, const BconvArgs &a, u32 table_key, u32 table_ntgt, u32 batch, bool pre, bool *done) {
   *done = false;
   if (c->bconv_mode == 1 || c->fixed_ws || a.nsrc > 32 || a.ntgt == 0 || c->N < BCONV_MFMA_BLOCK) return FHE_HIP_OK;
   const u32 NS = (a.nsrc + 7) / 8, ngroups = (a.ntgt + 3) / 4;
@@ -466,15 +461,20 @@ int try_bconv_mfma(fhe_hip_ctx *c, const char *name, const BconvArgs &a, u32 tab
   }
   BconvMfmaArgs m;
   m.out = a.out; m.src = a.src; m.table = table; m.tgt = c->d_bconv_tgt;
+  m.primes = a.primes; m.inv_m = a.inv_m; m.src_first = a.src_first;
   m.nsrc = a.nsrc; m.src_limbs = a.src_limbs; m.src_off = a.src_off;
   m.tgt_first = a.tgt_first; m.out_limbs = a.out_limbs; m.out_off = a.out_off; m.ntgt = a.ntgt; m.ngroups = ngroups;
   m.nblocks = nblocks; m.blocks_per_entry = bpe; m.N = c->N;
   const unsigned grid = nblocks < (u32)c->num_cus ? nblocks : (unsigned)c->num_cus;
-  switch (NS) {
-    case 1: TRY(launch_bconv_mfma<1>(c, name, m, grid, smem)); break;
-    case 2: TRY(launch_bconv_mfma<2>(c, name, m, grid, smem)); break;
-    case 3: TRY(launch_bconv_mfma<3>(c, name, m, grid, smem)); break;
-    default: TRY(launch_bconv_mfma<4>(c, name, m, grid, smem)); break;
+  switch (NS * 2 + (pre ? 1 : 0)) {
+    case 2: TRY((launch_bconv_mfma<1, false>(c, name, m, grid, smem))); break;
+    case 3: TRY((launch_bconv_mfma<1, true>(c, name, m, grid, smem))); break;
+    case 4: TRY((launch_bconv_mfma<2, false>(c, name, m, grid, smem))); break;
+    case 5: TRY((launch_bconv_mfma<2, true>(c, name, m, grid, smem))); break;
+    case 6: TRY((launch_bconv_mfma<3, false>(c, name, m, grid, smem))); break;
+    case 7: TRY((launch_bconv_mfma<3, true>(c, name, m, grid, smem))); break;
+    case 8: TRY((launch_bconv_mfma<4, false>(c, name, m, grid, smem))); break;
+    default: TRY((launch_bconv_mfma<4, true>(c, name, m, grid, smem))); break;
   }
   *done = true;
   return FHE_HIP_OK;
@@ -493,7 +493,7 @@ int dev_conv_to_special(fhe_hip_ctx *c, u64 *rop, u32 rop_limbs, u32 rop_off, co
   a.N = c->N;
   const dim3 grid((unsigned)(c->N / PW_THREADS), (c->K + BCONV_TC - 1) / BCONV_TC, batch);
   // pre_scaled: op already holds the digits [x_k * inv_k]_{q_k} (the producing inverse NTT was scaled by N^-1 * inv_k)
-  if (pre_scaled) { bool done; TRY(try_bconv_mfma(c, "bconv_modup", a, Li, c->K, batch, &done)); if (done) return FHE_HIP_OK; }
+  { bool done; TRY(try_bconv_mfma(c, "bconv_modup", a, Li, c->K, batch, pre_scaled, &done)); if (done) return FHE_HIP_OK; }
   if (pre_scaled) { if (c->sp) LAUNCH(c, "bconv_modup", (bconv_kernel<true, true>), grid, dim3(PW_THREADS), a); else LAUNCH(c, "bconv_modup", (bconv_kernel<false, true>), grid, dim3(PW_THREADS), a); }
   else { if (c->sp) LAUNCH(c, "bconv_modup", (bconv_kernel<true, false>), grid, dim3(PW_THREADS), a); else LAUNCH(c, "bconv_modup", (bconv_kernel<false, false>), grid, dim3(PW_THREADS), a); }
   return FHE_HIP_OK;
@@ -525,7 +525,7 @@ int dev_conv_to_normal(fhe_hip_ctx *c, u64 *rop, u32 L0, const u64 *op, u32 op_l
   a.N = c->N;
   const dim3 grid((unsigned)(c->N / PW_THREADS), (L0 + BCONV_TC - 1) / BCONV_TC, batch);
   // (the table of the special -> normal conversion does not depend on L0: a launch for fewer targets uses its first groups)
-  if (pre_scaled) { bool done; TRY(try_bconv_mfma(c, "bconv_moddown", a, 0, c->L, batch, &done)); if (done) return FHE_HIP_OK; }
+  { bool done; TRY(try_bconv_mfma(c, "bconv_moddown", a, 0, c->L, batch, pre_scaled, &done)); if (done) return FHE_HIP_OK; }
   if (pre_scaled) { if (c->sp) LAUNCH(c, "bconv_moddown", (bconv_kernel<true, true>), grid, dim3(PW_THREADS), a); else LAUNCH(c, "bconv_moddown", (bconv_kernel<false, true>), grid, dim3(PW_THREADS), a); }
   else { if (c->sp) LAUNCH(c, "bconv_moddown", (bconv_kernel<true, false>), grid, dim3(PW_THREADS), a); else LAUNCH(c, "bconv_moddown", (bconv_kernel<false, false>), grid, dim3(PW_THREADS), a); }
   return FHE_HIP_OK;

@@ -473,8 +473,21 @@ def test_base_conversion_on_the_matrix_cores_matches_the_vector_alu_kernel_and_t
             got[mode] = host(d)
             assert np.array_equal(got[mode], want), mode
             d = dev(ct)
-            g.rotate_non_ntt(gal, d, Li, batch=B)
+            g.rotate_non_ntt(gal, d, Li, batch=B)   # digits formed inside the kernel (lane-dependent source primes)
             assert np.array_equal(host(d), want_nn), mode
+            # the conversions as entry points of their own (base_converter.cpp:189-242, 297-311)
+            x = np.stack([rand_poly(o, range(Li), 530 + b) for b in range(2)])
+            rop = torch.zeros((2, Li + K, o.N), dtype=torch.int64, device="cuda")
+            g.mod_up(rop, dev(x), Li, batch=2)
+            assert np.array_equal(host(rop), np.stack([o.mod_up(x[b]) for b in range(2)])), mode
+            y = np.stack([rand_poly(o, list(range(Li)) + list(range(L, L + K)), 540 + b) for b in range(2)])
+            rop = torch.zeros((2, Li, o.N), dtype=torch.int64, device="cuda")
+            g.mod_down(rop, dev(y), Li, batch=2)
+            assert np.array_equal(host(rop), np.stack([o.mod_down(y[b]) for b in range(2)])), mode
+            sp_part = np.ascontiguousarray(y[:, Li:])
+            rop = torch.zeros((2, 1, o.N), dtype=torch.int64, device="cuda")
+            g.conv_to_normal(rop, dev(sp_part), 1, batch=2)   # one target: a quarter of a group
+            assert np.array_equal(host(rop)[1, 0], o.neg_approx_convert_to_normal_basis(sp_part[1], 0)), mode
         with pytest.raises(fhe_amd.FheHipError):
             g.set_tuning(fhe_amd.hip.TUNE_BCONV, 3)
     finally:
