@@ -1,37 +1,39 @@
 // bconv_mfma_kernels.h — fast basis conversion on the matrix cores of gfx950.
 //
-// internal::do_approximated_basis_conversion (reference src/base_converter.cpp:313-349) is a matrix product over the integers,
-//   T[coefficient][target] = sum_k digit_k[coefficient] * hat[target][k],      digit_k = [x_k * inv_k]_{src_k} < 2^62, hat < 2^62,
+// internal::do_approximated_basis_conversion (reference src/base_converter.cpp:313-349) is a matrix product,
+//   T[coefficient][target] = sum_k digit_k[coefficient] * hat[target][k]  (mod p_target),   digit_k = [x_k * inv_k]_{src_k} < 2^62,
 // followed by one reduction modulo the target prime.  bconv_kernel (pointwise_kernels.h) runs the product on the vector ALU: six
 // v_mad_u64_u32 per term, 180 of the ~250 instructions per (coefficient, target) at 30 source limbs, and is bound by VALU issue at
 // 0.22 of the HBM roofline.  Here the product runs on v_mfma_i32_16x16x64_i8 (16 cycles per 16 384 multiply-adds, a unit the
 // NTT kernels leave idle) and only the reduction stays on the vector ALU.
 //
-// Byte decomposition: every 64-bit operand v < 2^63 is written in balanced base 256, v = sum_i s_i 256^i with s_i in [-128, 127]
-// (the bytes of (v + C) ^ C, C = 0x8080808080808080).  Then T = sum_s S_s 256^s with the 15 byte-convolution sums
-// S_s = sum_k sum_{i+j=s} digit_{k,i} hat_{k,j}, |S_s| <= 8 * 32 * 2^14 = 2^22 for up to 32 source limbs.
+// Byte decomposition: a digit d < 2^63 is written in balanced base 256, d = sum_i d_i 256^i with d_i in [-128, 127] (the bytes of
+// (d + C) ^ C, C = 0x8080808080808080).  Modulo the target prime the weight of byte i moves into the constant:
+//   T * 2^64 = sum_k sum_i d_{k,i} * c_{t,k,i}   (mod p_t),      c_{t,k,i} = hat[t][k] * 256^i * 2^64 mod p_t   (< 2^62),
+// and with c in balanced bytes too, c = sum_j c_j 256^j, the integer U = sum_j 256^j S_j with the eight sums
+//   S_j = sum_{k,i} d_{k,i} c_{t,k,i,j},    |S_j| <= 8 * 32 * 2^14 = 2^22 for up to 32 source limbs,
+// is congruent to T * 2^64: a DENSE int8 product with K = 8 bytes x source limbs and 8 rows per target (a convolution over
+// byte weights i + j would need 15 rows per target, half of them structural zeros).
 //
 // MFMA tile (A: 16 rows x 64 k, B: 64 k x 16 columns, C: lane l holds rows 4(l>>4) + r, r = 0..3, of column l & 15):
 //   column  = coefficient (16 per tile);
 //   k slot  = (source limb, byte i of its digit): lane l of the B operand holds 16 bytes = the digits of limbs 8 st + 2(l>>4) and
 //             8 st + 2(l>>4) + 1 of its coefficient, i.e. two plain 64-bit loads (st = k-step, 8 limbs per MFMA);
-//   row     = 4 g + r  <->  (target 4 grp + g, byte weight s = 4 a + r), a = 0..3 numbering four tiles per group of four targets.
-// The A operand is the Toeplitz image of the hat bytes (hat_{k, s - i}, zero outside 0..7; built once per conversion table by
-// bconv_table_kernel, read from LDS).  After the four tiles of a group, lane (column c, g) holds all sixteen S_s of
-// (coefficient c, target 4 grp + g): no cross-lane step.  The accumulators start at 2^22 + (a byte of D), so every S is a
-// non-negative 24-bit number, where D = -2^22 (2^128 - 1)/255 mod p is chosen per target so that the whole offset is a multiple
-// of the target prime and never has to be taken out again.  T + offset is put together with 32-bit shift-adds, funnel shifts and
-// one carry chain (18 instructions), then taken through two 64-bit Montgomery reductions (the hat tables carry the factor 2^128).
-// ~45 VALU instructions per (coefficient, target) instead of ~250; half of the MFMA rows x k-slots are structural zeros of the
-// Toeplitz image.  MFMA and VALU work of one SIMD overlap only in part (tools/ubench/mfma_valu.hip: a wave of MFMAs leaves the
-// vector ALU ~40 % of its issue slots), so both counts matter.
+//   row     = 4 g + r  <->  (target 4 grp + g, byte j = 4 a + r), a = 0, 1 numbering two tiles per group of four targets.
+// The A operand (bytes of c, built on the host once per conversion table) is read from LDS.  After the two tiles of a group,
+// lane (column c, g) holds all eight S_j of (coefficient c, target 4 grp + g): no cross-lane step.  The accumulators start at
+// 2^22 + (a byte of D), so every S is a non-negative 24-bit number, where D = -2^22 (2^64 - 1)/255 mod p is chosen per target so
+// that the whole offset is a multiple of the target prime and never has to be taken out again.  U + offset (< 2^81) is put
+// together with 32-bit shift-adds, one funnel shift and one carry chain (10 instructions) and taken through ONE 64-bit Montgomery
+// reduction: ~25 VALU instructions and 8 NS / 4 MFMAs per (coefficient, target) instead of ~250 VALU instructions.
+// MFMA and VALU work of one SIMD overlap only in part (tools/ubench/mfma_valu.hip: a wave of MFMAs leaves the vector ALU ~40 % of
+// its issue slots), so both counts matter.
 //
 // Used when the conversion has at most 32 source limbs and the launch is large enough for persistent workgroups; everything
 // else runs bconv_kernel.  PRE: the digits arrive ready-made (the NTT-domain rotation pipeline: the producing inverse NTT carries
 // inv_k in its scaling); otherwise each lane forms the digits of the limbs it loads, [x_k * inv_k] mod src_k, once per block.
 #pragma once
 #include "pointwise_kernels.h"
-#include <type_traits>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -42,12 +44,12 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // per-prime constants of a conversion target (one 48-byte record, read by the lanes that fold for it)
 struct BconvTgt {
   u64 p, pinv;
-  u32 init[8];   // 2^22 + byte r of D: accumulator start values of byte weights 0..7 (weights 8..15 start at 2^22)
+  u32 init[8];   // 2^22 + byte j of D: accumulator start values
 };
 
 struct BconvMfmaArgs {
   u64 *out; const u64 *src;
-  const uint4 *table;     // [ngroups][2][NS][2][64] A fragments (16 bytes per lane) in the order the kernel consumes them: tile 2h + b at [h][st][b]
+  const uint4 *table;     // [ngroups][NS][2][64] A fragments (16 bytes per lane) in the order the kernel consumes them (host-built: fhe_hip.hip)
   const BconvTgt *tgt;    // [M]
   const PrimeC *primes;   // [M]      (digits formed in the kernel: source primes src_first + k)
   const u64 *inv_m;       // [nsrc]   (digits formed in the kernel) Montgomery form w.r.t. the source prime
@@ -63,60 +65,20 @@ __device__ __forceinline__ u64 balanced_bytes(u64 v) {
   return (v + C) ^ C;
 }
 
-// A fragments of one conversion table: hat_m = [ntgt][hat_stride] (times 2^128 mod the target prime, canonical)
-__global__ void bconv_table_kernel(uint4 *table, const u64 *hat_m, u32 hat_stride, u32 nsrc, u32 ntgt, u32 NS, u32 ngroups) {
-  const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= ngroups * 4 * NS * 64) return;
-  const u32 lane = idx & 63, f = idx >> 6, st = (f >> 1) % NS, hh = ((f >> 1) / NS) & 1, a4 = 2 * hh + (f & 1), grp = (f >> 1) / NS / 2;
-  const u32 m = lane & 15, kg = lane >> 4;
-  const u32 t = grp * 4 + (m >> 2);
-  const int s = (int)(4 * a4 + (m & 3));
-  u32 w[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int b = 0; b < 16; ++b) {
-    const u32 limb = 8 * st + 2 * kg + (b >> 3);
-    const int j = s - (b & 7);
-    u32 v = 0;
-    if (t < ntgt && limb < nsrc && j >= 0 && j <= 7) v = (u32)(balanced_bytes(hat_m[(u64)t * hat_stride + limb]) >> (8 * j)) & 0xFFu;
-    w[b >> 2] |= v << (8 * (b & 3));
-  }
-  table[idx] = make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-// Fold of the sixteen offset byte-convolution sums of one (coefficient, target) into the canonical residue, in two halves
-// (tiles 0, 1, then tiles 2, 3).  Word a of the sum collects Z_a = S_4a + 2^8 S_4a+1 (one 32-bit shift-add: both
-// < 2^23 + 2^8) and, 16 bits up, Y_a = S_4a+2 + 2^8 S_4a+3, whose upper half spills into word a + 1: V_a = (Y_a : Y_a-1) >> 16 is one
-// funnel shift, and one carry chain adds Z and V.
-struct BconvFoldState { u64 r1; u32 y1, cy; };
-// tiles 0, 1 (byte weights 0..7): words 0, 1 and their Montgomery reduction X0 * 2^-64 mod p, in (0, p]
+// Fold of the eight offset byte sums of one (coefficient, target) into the canonical residue.  Word a of U collects
+// Z_a = S_4a + 2^8 S_4a+1 (one 32-bit shift-add: both < 2^23 + 2^8) and, 16 bits up, Y_a = S_4a+2 + 2^8 S_4a+3, whose upper half
+// spills into word a + 1 (one funnel shift); one carry chain adds them.  U * 2^-64 mod p is the conversion's result.
 template <bool SP>
-__device__ __forceinline__ BconvFoldState bconv_fold_start(const v4i &c0, const v4i &c1, u64 p, u64 pinv) {
+__device__ __forceinline__ u64 bconv_mfma_fold(const v4i &c0, const v4i &c1, u64 p, u64 pinv) {
   const u32 z0 = ((u32)c0[1] << 8) + (u32)c0[0], y0 = ((u32)c0[3] << 8) + (u32)c0[2];
   const u32 z1 = ((u32)c1[1] << 8) + (u32)c1[0], y1 = ((u32)c1[3] << 8) + (u32)c1[2];
   u32 cy;
   const u32 w0 = __builtin_addc(z0, y0 << 16, 0u, &cy);
   const u32 w1 = __builtin_addc(z1, __builtin_amdgcn_alignbit(y1, y0, 16), cy, &cy);
+  const u32 w2 = (y1 >> 16) + cy;                                  // < 2^17
   PrimeC PT;
   PT.p = p; PT.pinv = pinv; PT.p1 = (u32)(p >> 32);
-  BconvFoldState s;
-  s.r1 = mont_reduce<SP>(0, pair64(w0, w1), PT);
-  s.y1 = y1; s.cy = cy;
-  return s;
-}
-// tiles 2, 3 (byte weights 8..15): words 2..4, joined with the first half and reduced once more: (T + k p) * 2^-128 mod p, canonical
-template <bool SP>
-__device__ __forceinline__ u64 bconv_fold_finish(const v4i &c2, const v4i &c3, const BconvFoldState &s, u64 p, u64 pinv) {
-  const u32 z2 = ((u32)c2[1] << 8) + (u32)c2[0], y2 = ((u32)c2[3] << 8) + (u32)c2[2];
-  const u32 z3 = ((u32)c3[1] << 8) + (u32)c3[0], y3 = ((u32)c3[3] << 8) + (u32)c3[2];
-  u32 cy;
-  const u32 w2 = __builtin_addc(z2, __builtin_amdgcn_alignbit(y2, s.y1, 16), s.cy, &cy);
-  const u32 w3 = __builtin_addc(z3, __builtin_amdgcn_alignbit(y3, y2, 16), cy, &cy);
-  const u32 w4 = (y3 >> 16) + cy;
-  PrimeC PT;
-  PT.p = p; PT.pinv = pinv; PT.p1 = (u32)(p >> 32);
-  const u64 w_lo = pair64(w2, w3) + s.r1;
-  const u64 w_hi = (u64)w4 + (w_lo < s.r1 ? 1u : 0u);
-  return csub(mont_reduce<SP>(w_hi, w_lo, PT), p);
+  return csub(mont_reduce<SP>((u64)w2, pair64(w0, w1), PT), p);    // (w2, p + w2] -> [0, p)
 }
 
 template <bool SP, int NS, bool PRE>
@@ -124,17 +86,17 @@ __global__ __launch_bounds__(BCONV_MFMA_THREADS) void bconv_mfma_kernel(BconvMfm
   extern __shared__ __attribute__((aligned(16))) unsigned char bconv_smem[];
   uint4 *tab = reinterpret_cast<uint4 *>(bconv_smem);
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
-  const u32 nfrag = a.ngroups * 4 * NS * 64;
+  const u32 nfrag = a.ngroups * 2 * NS * 64;
   for (u32 i = tid; i < nfrag; i += BCONV_MFMA_THREADS) tab[i] = a.table[i];
   __syncthreads();
   const u32 last = a.nsrc - 1;
-  // A fragments: one cyclic stream of phases (a group's tiles 0,1 over all k-steps, then its tiles 2,3), PH fragments per phase,
-  // held in a ring of R registers sets: the fragment R positions ahead is requested right after the multiply-adds of the current
-  // one were issued, so an LDS read has >= 16 MFMAs to arrive.  The stream wraps from the last group to the first.
+  // A fragments: one cyclic stream (group, k-step, tile), PH per group, held in a ring of R register sets: the fragment R
+  // positions ahead is requested right after the multiply-adds of the current one were issued, so an LDS read has >= 16 MFMAs
+  // to arrive.  The stream wraps from the last group to the first.
   constexpr int PH = 2 * NS, R = (PH % 4 == 0) ? 4 : PH;
   const uint4 *tq = tab + lane;
-  const u32 nq = a.ngroups * 2 * PH * 64;   // table length in uint4
-  u32 qc = 0, qx = PH * 64 < nq ? PH * 64 : 0;   // offsets of the current and the next phase
+  const u32 nq = a.ngroups * PH * 64;            // table length in uint4
+  u32 qc = 0, qx = PH * 64 < nq ? PH * 64 : 0;   // offsets of the current and the next group
   uint4 fr[R];
 #pragma unroll
   for (int n = 0; n < R; ++n) fr[n] = tq[n * 64];
@@ -176,12 +138,10 @@ __global__ __launch_bounds__(BCONV_MFMA_THREADS) void bconv_mfma_kernel(BconvMfm
 #pragma unroll
     for (int st = 0; st < NS; ++st) request(sp, st);
   }
-  const v4i acc0 = v4i{BCONV_MFMA_ACC0, BCONV_MFMA_ACC0, BCONV_MFMA_ACC0, BCONV_MFMA_ACC0};
   const BconvTgt *tp = a.tgt + a.tgt_first;
-  v4i acc[4][4];
-  // one half of a group's MFMAs (tiles 2 H, 2 H + 1 over all k-steps)
-  auto phase = [&](auto H, const v4i &c_lo, const v4i &c_hi, auto &&after_step) {
-    constexpr int h = decltype(H)::value;
+  v4i acc[2][4];
+  // a group's MFMAs: tiles 0, 1 over all k-steps
+  auto group_mfma = [&](const v4i &c_lo, const v4i &c_hi, auto &&after_step) {
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
 #pragma unroll
@@ -191,15 +151,15 @@ __global__ __launch_bounds__(BCONV_MFMA_THREADS) void bconv_mfma_kernel(BconvMfm
         const v4i A = v4i{(int)f.x, (int)f.y, (int)f.z, (int)f.w};
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
-          acc[2 * h + b][ct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B[ct][st], st == 0 ? (b == 0 ? c_lo : c_hi) : acc[2 * h + b][ct], 0, 0, 0);
+          acc[b][ct] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A, B[ct][st], st == 0 ? (b == 0 ? c_lo : c_hi) : acc[b][ct], 0, 0, 0);
         const int m = n + R;
         fr[n % R] = m < PH ? tq[qc + m * 64] : tq[qx + (m - PH) * 64];
       }
       after_step(st);
       __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the LDS reads to just before their use)
     }
+    qc = qx; qx = qx + PH * 64; qx = qx < nq ? qx : 0;
   };
-  auto advance = [&]() { qc = qx; qx = qx + PH * 64; qx = qx < nq ? qx : 0; };
 
   for (u32 blk = blockIdx.x; blk < a.nblocks; blk += gridDim.x) {   // bounded: every wave leaves after its last block
     const u32 e = blk / a.blocks_per_entry;
@@ -228,17 +188,13 @@ __global__ __launch_bounds__(BCONV_MFMA_THREADS) void bconv_mfma_kernel(BconvMfm
         pn = tp[tcn].p; pinvn = tp[tcn].pinv;
         i0n = *reinterpret_cast<const v4i *>(tp[tcn].init); i1n = *reinterpret_cast<const v4i *>(tp[tcn].init + 4);
       }
-      phase(std::integral_constant<int, 0>(), i0, i1, [&](int) {});
-      advance();
       // the next block's digits are requested during the last group, k-step by k-step as the registers fall free
-      if (grp + 1 == a.ngroups) phase(std::integral_constant<int, 1>(), acc0, acc0, [&](int st) { request(spn, st); });
-      else phase(std::integral_constant<int, 1>(), acc0, acc0, [&](int) {});
-      advance();
+      if (grp + 1 == a.ngroups) group_mfma(i0, i1, [&](int st) { request(spn, st); });
+      else group_mfma(i0, i1, [&](int) {});
       u64 *op = a.out + ((u64)e * a.out_limbs + a.out_off + tc) * a.N + d;
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
-        const BconvFoldState fs = bconv_fold_start<SP>(acc[0][ct], acc[1][ct], p, pinv);
-        const u64 r = bconv_fold_finish<SP>(acc[2][ct], acc[3][ct], fs, p, pinv);
+        const u64 r = bconv_mfma_fold<SP>(acc[0][ct], acc[1][ct], p, pinv);
         DBG_RANGE(r, p, 13);
         if (t < a.ntgt) op[16 * ct] = r;
       }

@@ -74,6 +74,7 @@ struct fhe_hip_ctx {
   // conversion tables, built on first use (key: 0 = special -> normal, Li = normal limbs 0..Li-1 -> special)
   BconvTgt *d_bconv_tgt = nullptr;               // [M]  per-prime constants of a conversion target (accumulator start values)
   std::map<u32, uint4 *> bconv_tables;
+  std::vector<u64> h_neg_hat, h_hat_qj_pi;       // host copies of d_neg_hat_pi_qj_m / d_hat_qj_pi_m (the byte images are built from them)
   uint32_t bconv_mode = 0;                       // FHE_HIP_TUNE_BCONV: 0 = by shape and size, 1 = vector-ALU kernel only, 2 = MFMA kernel whenever the shape allows
   bool bconv_attr_set[4][2] = {{false, false}, {false, false}, {false, false}, {false, false}};
   // encoder (fhe_hip_encode / _decode), built on first use: psi^brv(i) as complex doubles, the generator-3 slot index map, and the
@@ -439,11 +440,11 @@ int launch_bconv_mfma(fhe_hip_ctx *c, const char *name, const BconvMfmaArgs &m, 
   HIPCHK(c, hipGetLastError());
   return FHE_HIP_OK;
 }
-int try_bconv_mfma(fhe_hip_ctx *c, const char *name, const BconvArgs &a, u32 table_key, u32 table_ntgt, u32 batch, bool pre, bool *done) {
+int try_bconv_mfma(fhe_hip_ctx *c, const char *name, const BconvArgs &a, const u64 *hat_h, u32 table_key, u32 table_ntgt, u32 batch, bool pre, bool *done) {
   *done = false;
   if (c->bconv_mode == 1 || c->fixed_ws || a.nsrc > 32 || a.ntgt == 0 || c->N < BCONV_MFMA_BLOCK) return FHE_HIP_OK;
   const u32 NS = (a.nsrc + 7) / 8, ngroups = (a.ntgt + 3) / 4;
-  const size_t smem = (size_t)ngroups * 4 * NS * 64 * 16;
+  const size_t smem = (size_t)ngroups * 2 * NS * 64 * 16;
   if (smem > 156 * 1024) return FHE_HIP_OK;
   const u32 bpe = (u32)(c->N / BCONV_MFMA_BLOCK), nblocks = bpe * batch;
   if (c->bconv_mode == 0 && nblocks < 2 * (u32)c->num_cus) return FHE_HIP_OK;   // too small to pay for the per-workgroup table load
@@ -451,13 +452,32 @@ int try_bconv_mfma(fhe_hip_ctx *c, const char *name, const BconvArgs &a, u32 tab
   auto it = c->bconv_tables.find(table_key);
   if (it != c->bconv_tables.end()) table = it->second;
   else {
-    // all table_ntgt targets of the conversion (a launch for fewer targets reads a prefix: the image is grouped by target)
-    const u32 tgroups = (table_ntgt + 3) / 4, nfrag = tgroups * 4 * NS * 64;
-    HIPCHK(c, hipMalloc((void **)&table, (size_t)nfrag * 16));
+    // all table_ntgt targets of the conversion (a launch for fewer targets reads a prefix: the image is grouped by target).
+    // Fragment ((grp NS + st) 2 + tile), lane (row m, k-group kg), byte b: source limb 8 st + 2 kg + (b >> 3), digit byte i = b & 7,
+    // target 4 grp + (m >> 2), constant byte j = 4 tile + (m & 3) of c = hat * 256^i * 2^64 mod p in balanced bytes.
+    const u32 tgroups = (table_ntgt + 3) / 4, nfrag = tgroups * 2 * NS * 64;
+    std::vector<unsigned char> img((size_t)nfrag * 16, 0);
+    for (u32 t = 0; t < table_ntgt; ++t) {
+      const u64 p = c->primes[a.tgt_first + t];
+      const u64 rinv = h_invmod(h_to_mont(1, p), p);   // 2^-64 mod p
+      for (u32 k = 0; k < a.nsrc; ++k) {
+        u64 cki = h_mulmod(hat_h[(size_t)t * a.hat_stride + k], rinv, p);   // hat * 2^64 mod p (the stored form carries 2^128)
+        for (u32 i = 0; i < 8; ++i) {
+          const u64 bal = (cki + 0x8080808080808080ull) ^ 0x8080808080808080ull;
+          const u32 st = k / 8, kg = (k % 8) / 2, b = (k % 2) * 8 + i;
+          for (u32 j = 0; j < 8; ++j) {
+            const u32 m = (t % 4) * 4 + (j % 4), tile = j / 4, lane = kg * 16 + m;
+            img[((((size_t)(t / 4) * NS + st) * 2 + tile) * 64 + lane) * 16 + b] = (unsigned char)(bal >> (8 * j));
+          }
+          cki = h_mulmod(cki, 256, p);
+        }
+      }
+    }
+    HIPCHK(c, hipMalloc((void **)&table, img.size()));
     c->bconv_tables[table_key] = table;
     HIPCHK(c, prof_chain_break(c));
-    hipLaunchKernelGGL(bconv_table_kernel, dim3((nfrag + 255) / 256), dim3(256), 0, c->stream, table, a.hat_m, a.hat_stride, a.nsrc, table_ntgt, NS, tgroups);
-    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(table, img.data(), img.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // (img goes out of scope)
   }
   BconvMfmaArgs m;
   m.out = a.out; m.src = a.src; m.table = table; m.tgt = c->d_bconv_tgt;
@@ -493,7 +513,7 @@ int dev_conv_to_special(fhe_hip_ctx *c, u64 *rop, u32 rop_limbs, u32 rop_off, co
   a.N = c->N;
   const dim3 grid((unsigned)(c->N / PW_THREADS), (c->K + BCONV_TC - 1) / BCONV_TC, batch);
   // pre_scaled: op already holds the digits [x_k * inv_k]_{q_k} (the producing inverse NTT was scaled by N^-1 * inv_k)
-  { bool done; TRY(try_bconv_mfma(c, "bconv_modup", a, Li, c->K, batch, pre_scaled, &done)); if (done) return FHE_HIP_OK; }
+  { bool done; TRY(try_bconv_mfma(c, "bconv_modup", a, c->h_hat_qj_pi.data() + (size_t)(Li - 2) * c->K * c->L, Li, c->K, batch, pre_scaled, &done)); if (done) return FHE_HIP_OK; }
   if (pre_scaled) { if (c->sp) LAUNCH(c, "bconv_modup", (bconv_kernel<true, true>), grid, dim3(PW_THREADS), a); else LAUNCH(c, "bconv_modup", (bconv_kernel<false, true>), grid, dim3(PW_THREADS), a); }
   else { if (c->sp) LAUNCH(c, "bconv_modup", (bconv_kernel<true, false>), grid, dim3(PW_THREADS), a); else LAUNCH(c, "bconv_modup", (bconv_kernel<false, false>), grid, dim3(PW_THREADS), a); }
   return FHE_HIP_OK;
@@ -525,7 +545,7 @@ int dev_conv_to_normal(fhe_hip_ctx *c, u64 *rop, u32 L0, const u64 *op, u32 op_l
   a.N = c->N;
   const dim3 grid((unsigned)(c->N / PW_THREADS), (L0 + BCONV_TC - 1) / BCONV_TC, batch);
   // (the table of the special -> normal conversion does not depend on L0: a launch for fewer targets uses its first groups)
-  { bool done; TRY(try_bconv_mfma(c, "bconv_moddown", a, 0, c->L, batch, pre_scaled, &done)); if (done) return FHE_HIP_OK; }
+  { bool done; TRY(try_bconv_mfma(c, "bconv_moddown", a, c->h_neg_hat.data(), 0, c->L, batch, pre_scaled, &done)); if (done) return FHE_HIP_OK; }
   if (pre_scaled) { if (c->sp) LAUNCH(c, "bconv_moddown", (bconv_kernel<true, true>), grid, dim3(PW_THREADS), a); else LAUNCH(c, "bconv_moddown", (bconv_kernel<false, true>), grid, dim3(PW_THREADS), a); }
   else { if (c->sp) LAUNCH(c, "bconv_moddown", (bconv_kernel<true, false>), grid, dim3(PW_THREADS), a); else LAUNCH(c, "bconv_moddown", (bconv_kernel<false, false>), grid, dim3(PW_THREADS), a); }
   return FHE_HIP_OK;
@@ -925,14 +945,15 @@ int fhe_hip_ctx_create(fhe_hip_ctx **out, uint32_t logN, uint32_t L, uint32_t K,
   if ((rc = upload(c, &c->d_hat_pi_inv_m, hat_pi_inv)) || (rc = upload(c, &c->d_neg_hat_pi_qj_m, neg_hat)) || (rc = upload(c, &c->d_Pinv_qj_m, Pinv)) ||
       (rc = upload(c, &c->d_hat_qj_inv_m, hat_qj_inv)) || (rc = upload(c, &c->d_hat_qj_pi_m, hat_qj_pi)) || (rc = upload(c, &c->d_qinv_m, qinv)))
     return fail(rc);
+  c->h_neg_hat = neg_hat; c->h_hat_qj_pi = hat_qj_pi;
   {
-    // bconv_mfma_kernel's accumulators start at 2^22 + a byte of D, D = -2^22 (2^128 - 1)/255 mod p: the sixteen byte weights
+    // bconv_mfma_kernel's accumulators start at 2^22 + a byte of D, D = -2^22 (2^64 - 1)/255 mod p: the eight byte weights
     // then carry a multiple of p into the sum
     std::vector<BconvTgt> tg(M);
     for (uint32_t m = 0; m < M; ++m) {
       const u64 p = primes[m];
       u64 b = 0;
-      for (int s = 0; s < 16; ++s) b = (b + h_powmod(2, 22 + 8 * s, p)) % p;
+      for (int s = 0; s < 8; ++s) b = (b + h_powmod(2, 22 + 8 * s, p)) % p;
       const u64 D = (p - b) % p;
       tg[m].p = p; tg[m].pinv = pc[m].pinv;
       for (int r = 0; r < 8; ++r) tg[m].init[r] = (1u << 22) + (u32)((D >> (8 * r)) & 0xFF);
