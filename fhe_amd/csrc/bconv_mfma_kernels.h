@@ -47,6 +47,8 @@ struct BconvTgt {
   u32 init[8];   // 2^22 + byte j of D: accumulator start values
 };
 
+static_assert(sizeof(BconvTgt) == 48, "the kernel copies three uint4 per record");
+
 struct BconvMfmaArgs {
   u64 *out; const u64 *src;
   const uint4 *table;     // [ngroups][NS][2][64] A fragments (16 bytes per lane) in the order the kernel consumes them (host-built: fhe_hip.hip)
@@ -88,6 +90,11 @@ __global__ __launch_bounds__(BCONV_MFMA_THREADS) void bconv_mfma_kernel(BconvMfm
   const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
   const u32 nfrag = a.ngroups * 2 * NS * 64;
   for (u32 i = tid; i < nfrag; i += BCONV_MFMA_THREADS) tab[i] = a.table[i];
+  // the targets' constants behind the table (3 uint4 per record).  Inside the block loop nothing but the digits is LOADED from
+  // global memory: vector-memory operations complete in order, so waiting for any younger load would wait for the prefetched
+  // digits of the next block as well.
+  uint4 *tconst = tab + nfrag;
+  for (u32 i = tid; i < a.ntgt * 3; i += BCONV_MFMA_THREADS) tconst[i] = reinterpret_cast<const uint4 *>(a.tgt + a.tgt_first)[i];
   __syncthreads();
   const u32 last = a.nsrc - 1;
   // A fragments: one cyclic stream (group, k-step, tile), PH per group, held in a ring of R register sets: the fragment R
@@ -100,9 +107,12 @@ __global__ __launch_bounds__(BCONV_MFMA_THREADS) void bconv_mfma_kernel(BconvMfm
   uint4 fr[R];
 #pragma unroll
   for (int n = 0; n < R; ++n) fr[n] = tq[n * 64];
-  // digits of the block as B operands: B[ct][st] = limbs 8 st + 2 g, + 1 of coefficient 16 ct + col.  They are requested for the
-  // NEXT block during the last group of the current one, k-step by k-step as the registers fall free, and arrive raw; each block
-  // starts by turning them into balanced bytes.
+  // digits of the block as B operands: B[ct][st] = limbs 8 st + 2 g, + 1 of coefficient 32 (ct >> 1) + 2 col + (ct & 1) of the wave's
+  // 64 (a lane's pair of adjacent coefficients comes from one 16-byte load and leaves in one 16-byte store).  The NEXT block's are
+  // requested (raw, into a second register set) as soon as the current block's have been turned into balanced bytes, so the
+  // loads have a whole block of MFMAs and folds to arrive: one persistent workgroup per CU has no other waves to hide them.
+  // Measured (round 3): with the MFMAs or the fold compiled out the kernel takes the same 0.98 ms per 4 GB at C4's shape, with
+  // the LDS reads compiled out too: the kernel moves 4.1 TB/s and is bound by the memory system, not by either unit.
   // (limbs beyond the source basis meet zero rows of the table: any valid address will do)
   u32 kidx[NS][2];
 #pragma unroll
@@ -123,25 +133,26 @@ __global__ __launch_bounds__(BCONV_MFMA_THREADS) void bconv_mfma_kernel(BconvMfm
   };
   auto block_src = [&](u32 blk) {
     const u32 e = blk / a.blocks_per_entry;
-    return a.src + ((u64)e * a.src_limbs + a.src_off) * a.N + (u64)(blk % a.blocks_per_entry) * BCONV_MFMA_BLOCK + wave * 64 + col;
+    return a.src + ((u64)e * a.src_limbs + a.src_off) * a.N + (u64)(blk % a.blocks_per_entry) * BCONV_MFMA_BLOCK + wave * 64 + 2 * col;
   };
   v4i B[4][NS];
-  auto request = [&](const u64 *sp, int st) {
+  u64 Bn[4][NS][2];
+  auto request = [&](const u64 *sp) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      const u64 x0 = sp[(u64)kidx[st][0] * a.N + 16 * ct], x1 = sp[(u64)kidx[st][1] * a.N + 16 * ct];
-      B[ct][st] = v4i{(int)(u32)x0, (int)(u32)(x0 >> 32), (int)(u32)x1, (int)(u32)(x1 >> 32)};
-    }
+    for (int st = 0; st < NS; ++st)
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const ulonglong2 v = ld2(sp + (u64)kidx[st][q] * a.N + 32 * pr);
+          Bn[2 * pr][st][q] = v.x; Bn[2 * pr + 1][st][q] = v.y;
+        }
   };
-  if (blockIdx.x < a.nblocks) {
-    const u64 *sp = block_src(blockIdx.x);
-#pragma unroll
-    for (int st = 0; st < NS; ++st) request(sp, st);
-  }
-  const BconvTgt *tp = a.tgt + a.tgt_first;
+  if (blockIdx.x < a.nblocks) request(block_src(blockIdx.x));
+  const BconvTgt *tp = reinterpret_cast<const BconvTgt *>(tconst);
   v4i acc[2][4];
   // a group's MFMAs: tiles 0, 1 over all k-steps
-  auto group_mfma = [&](const v4i &c_lo, const v4i &c_hi, auto &&after_step) {
+  auto group_mfma = [&](const v4i &c_lo, const v4i &c_hi) {
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
 #pragma unroll
@@ -155,7 +166,6 @@ __global__ __launch_bounds__(BCONV_MFMA_THREADS) void bconv_mfma_kernel(BconvMfm
         const int m = n + R;
         fr[n % R] = m < PH ? tq[qc + m * 64] : tq[qx + (m - PH) * 64];
       }
-      after_step(st);
       __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the LDS reads to just before their use)
     }
     qc = qx; qx = qx + PH * 64; qx = qx < nq ? qx : 0;
@@ -163,18 +173,19 @@ __global__ __launch_bounds__(BCONV_MFMA_THREADS) void bconv_mfma_kernel(BconvMfm
 
   for (u32 blk = blockIdx.x; blk < a.nblocks; blk += gridDim.x) {   // bounded: every wave leaves after its last block
     const u32 e = blk / a.blocks_per_entry;
-    const u64 d = (u64)(blk % a.blocks_per_entry) * BCONV_MFMA_BLOCK + wave * 64 + col;
+    const u64 d = (u64)(blk % a.blocks_per_entry) * BCONV_MFMA_BLOCK + wave * 64 + 2 * col;
     const u32 nblk = blk + gridDim.x;
-    const u64 *spn = block_src(nblk < a.nblocks ? nblk : blk);   // (after the last block: a harmless re-read of this one)
 #pragma unroll
     for (int st = 0; st < NS; ++st)
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
-        const u64 x0 = balanced_bytes(digit(pair64((u32)B[ct][st][0], (u32)B[ct][st][1]), kidx[st][0]));
-        const u64 x1 = balanced_bytes(digit(pair64((u32)B[ct][st][2], (u32)B[ct][st][3]), kidx[st][1]));
+        const u64 x0 = balanced_bytes(digit(Bn[ct][st][0], kidx[st][0])), x1 = balanced_bytes(digit(Bn[ct][st][1], kidx[st][1]));
         B[ct][st] = v4i{(int)(u32)x0, (int)(u32)(x0 >> 32), (int)(u32)x1, (int)(u32)(x1 >> 32)};
       }
-    // target constants one group ahead (a global load waited for where it is used costs its whole latency per group)
+    __builtin_amdgcn_sched_barrier(0);
+    if (nblk < a.nblocks) request(block_src(nblk));
+    __builtin_amdgcn_sched_barrier(0);
+    // target constants one group ahead (LDS)
     u32 tcn = g < a.ntgt ? g : a.ntgt - 1;
     u64 pn = tp[tcn].p, pinvn = tp[tcn].pinv;
     v4i i0n = *reinterpret_cast<const v4i *>(tp[tcn].init), i1n = *reinterpret_cast<const v4i *>(tp[tcn].init + 4);
@@ -188,15 +199,12 @@ __global__ __launch_bounds__(BCONV_MFMA_THREADS) void bconv_mfma_kernel(BconvMfm
         pn = tp[tcn].p; pinvn = tp[tcn].pinv;
         i0n = *reinterpret_cast<const v4i *>(tp[tcn].init); i1n = *reinterpret_cast<const v4i *>(tp[tcn].init + 4);
       }
-      // the next block's digits are requested during the last group, k-step by k-step as the registers fall free
-      if (grp + 1 == a.ngroups) group_mfma(i0, i1, [&](int st) { request(spn, st); });
-      else group_mfma(i0, i1, [&](int) {});
+      group_mfma(i0, i1);
       u64 *op = a.out + ((u64)e * a.out_limbs + a.out_off + tc) * a.N + d;
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const u64 r = bconv_mfma_fold<SP>(acc[0][ct], acc[1][ct], p, pinv);
-        DBG_RANGE(r, p, 13);
-        if (t < a.ntgt) op[16 * ct] = r;
+      for (int pr = 0; pr < 2; ++pr) {
+        const u64 r0 = bconv_mfma_fold<SP>(acc[0][2 * pr], acc[1][2 * pr], p, pinv), r1 = bconv_mfma_fold<SP>(acc[0][2 * pr + 1], acc[1][2 * pr + 1], p, pinv);
+        if (t < a.ntgt) st2c(op + 32 * pr, r0, r1, p, 13);
       }
     }
   }

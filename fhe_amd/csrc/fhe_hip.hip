@@ -444,8 +444,8 @@ int try_bconv_mfma(fhe_hip_ctx *c, const char *name, const BconvArgs &a, const u
   *done = false;
   if (c->bconv_mode == 1 || c->fixed_ws || a.nsrc > 32 || a.ntgt == 0 || c->N < BCONV_MFMA_BLOCK) return FHE_HIP_OK;
   const u32 NS = (a.nsrc + 7) / 8, ngroups = (a.ntgt + 3) / 4;
-  const size_t smem = (size_t)ngroups * 2 * NS * 64 * 16;
-  if (smem > 156 * 1024) return FHE_HIP_OK;
+  const size_t smem = (size_t)ngroups * 2 * NS * 64 * 16 + (size_t)a.ntgt * sizeof(BconvTgt);   // byte image + the targets' constants
+  if (smem > 158 * 1024) return FHE_HIP_OK;
   const u32 bpe = (u32)(c->N / BCONV_MFMA_BLOCK), nblocks = bpe * batch;
   if (c->bconv_mode == 0 && nblocks < 2 * (u32)c->num_cus) return FHE_HIP_OK;   // too small to pay for the per-workgroup table load
   uint4 *table = nullptr;
