@@ -149,8 +149,10 @@ def dominant_kernel_bytes(workload, N, Li, K, units_per_launch):
         shared = 8 * N * (2 * Li * Li + units_per_launch * (Li * Li + 4 * Li))
         per_op = 8 * N * units_per_launch * (2 * Li * Li + Li * Li + 4 * Li)
         return shared, per_op
-    if workload == "c4":    # mod-down of both halves of a rotation in one launch: 2 x (K special limbs in, Li normal limbs out)
-        b = units_per_launch * 2 * 8 * N * (Li + K)
+    if workload == "c4":
+        # ntt_rows8_fwd_kernel<SP, 4>, the rotation's last launch (both halves): per ciphertext and normal limb the two column-pass
+        # limbs in, galois(ax) and galois(bx) of the input, two result limbs out; the 2*Li key limbs once per launch
+        b = 8 * N * Li * (6 * units_per_launch + 2)
         return b, b
     b = units_per_launch * 16 * N  # ntt / c2: the cols + rows pair is one limb-NTT = read N + write N words
     return b, b
@@ -272,7 +274,7 @@ def launch_ranks(n):
     return next((rc for rc in rcs if rc), 0)
 
 
-KERNEL_SOURCES = ("modarith.h", "ntt_kernels.h", "pointwise_kernels.h", "fhe_hip.hip")
+KERNEL_SOURCES = ("modarith.h", "ntt_kernels.h", "pointwise_kernels.h", "bconv_mfma_kernels.h", "fhe_hip.hip")
 
 
 def kernel_source_sha16():
@@ -456,15 +458,17 @@ class Setup:
         kms = lambda name: prof.get(name, (0, 0.0))  # noqa: E731
         if w in MULT:
             launches, ms = kms("relin_rows_mac")
-            kname = "relin_rows8p_mac_kernel"
+            kname = "relin_rows4_mac_kernel" if os.environ.get("FHE_BENCH_RELIN_KERNEL", "1") != "0" else "relin_rows8p_mac_kernel"
             units_per_launch = B
         elif w in GENERIC:  # the "next" rows: the whole pipeline of the op against its algorithmic bytes
             launches, ms = steps, sum(v[1] for v in prof.values())
             kname = "whole pipeline: " + " + ".join(sorted(prof))
             units_per_launch = B
         elif w == "c4":
-            launches, ms = kms("bconv_moddown")   # the larger of the two conversion launches: both halves' mod-down in one
-            kname = "bconv_kernel (mod-down of both halves, one launch)"
+            # longest launch of the step since the base conversions moved to the matrix cores: the last forward row pass with the
+            # normal limbs' key product, the mod-down tail and + galois(bx) fused (both halves in one launch)
+            launches, ms = kms("ntt_fwd_rows_rotdown")
+            kname = "ntt_rows8_fwd_kernel<SP, 4> (row pass + key product of the normal limbs + mod-down tail, both halves in one launch)"
             units_per_launch = B
         elif kms("ntt_fwd_overlapped")[0]:
             # N >= 2^15: the library issues the call's chunks on two internal streams (column pass of one chunk under the row pass of
@@ -496,6 +500,12 @@ class Setup:
         roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 bytes_key: alg, "avg_launch_ms": avg_ms, "launches": launches}
+        if w == "c4" and kms("bconv_moddown")[0]:
+            # the mod-down base conversion (bconv_mfma_kernel when the shape allows): 2 x (K special limbs in, Li normal limbs out) per ciphertext
+            bl, bms = kms("bconv_moddown")
+            bb = B * 2 * 8 * N * (Li + K)
+            roof["base_conversion"] = {"kernel": "bconv_moddown (both halves in one launch)", "alg_bytes_per_launch": bb, "avg_launch_ms": bms / bl,
+                                       "achieved": bb / (bms / bl * 1e-3) / 1e9, "frac": bb / (bms / bl * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if w in MULT:
             roof["bytes_note"] = ("bytes this launch of the two-kernel relinearisation has to move once: 2*Li^2 key limbs, per ciphertext the Li^2 "
                                   "column-pass limbs (an intermediate of this design, not algorithmic bytes of the operation), 2*Li addends, 2*Li results")

@@ -29,13 +29,13 @@ M=$GRAFT_REPO_ROOT/tools
 for wl in $WLS; do
   case $wl in
     c3) python3 $M/make_traffic_json.py $OUT/pmc_summary_c3.txt c3 "c3, default batch per launch, N=2^16 Li=30" $OUT/traffic_c3.json relin_rows
-        python3 $M/make_valu_json.py $OUT/valu_c3 c3 "c3, default batch per launch, N=2^16 Li=30" $OUT/valu_c3.json relin_rows8p ;;
+        python3 $M/make_valu_json.py $OUT/valu_c3 c3 "c3, default batch per launch, N=2^16 Li=30" $OUT/valu_c3.json relin_rows ;;
     ntt) python3 $M/make_traffic_json.py $OUT/pmc_summary_ntt.txt ntt "ntt, 2048 limbs/launch, N=2^16" $OUT/traffic_ntt.json "ntt_cols_kernel<true, false" "ntt_rows8_fwd_kernel<true, 0"
         python3 $M/make_valu_json.py $OUT/valu_ntt ntt "ntt, 2048 limbs/launch, N=2^16" $OUT/valu_ntt.json "ntt_cols_kernel<true, false" "ntt_rows8_fwd_kernel<true, 0" ;;
     c2) python3 $M/make_traffic_json.py $OUT/pmc_summary_c2.txt c2 "c2, 8192 limbs/launch, N=2^14 (one-pass forward kernel)" $OUT/traffic_c2.json "ntt_onepass_fwd_kernel<true"
         python3 $M/make_valu_json.py $OUT/valu_c2 c2 "c2, 8192 limbs/launch, N=2^14 (one-pass forward kernel)" $OUT/valu_c2.json "ntt_onepass_fwd_kernel<true" ;;
-    c4) LAUNCHES_PER_STEP=2 python3 $M/make_traffic_json.py $OUT/pmc_summary_c4.txt c4 "c4, default batch per launch, N=2^16 Li=K=30 (mod-down launch: both halves)" $OUT/traffic_c4.json bconv_kernel
-        python3 $M/make_valu_json.py $OUT/valu_c4 c4 "c4, default batch per launch, N=2^16 Li=K=30 (mod-down launch: both halves)" $OUT/valu_c4.json bconv_kernel ;;
+    c4) python3 $M/make_traffic_json.py $OUT/pmc_summary_c4.txt c4 "c4, default batch per launch, N=2^16 Li=K=30 (last forward row pass: key product + mod-down tail, both halves)" $OUT/traffic_c4.json "ntt_rows8_fwd_kernel<true, 4"
+        python3 $M/make_valu_json.py $OUT/valu_c4 c4 "c4, default batch per launch, N=2^16 Li=K=30 (last forward row pass: key product + mod-down tail, both halves)" $OUT/valu_c4.json "ntt_rows8_fwd_kernel<true, 4" ;;
   esac
 done
 # raw counter dumps are large: keep the summaries and the JSONs

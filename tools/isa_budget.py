@@ -28,23 +28,25 @@ def body_of(sym):
 def count(lines):
     ops = collections.Counter()
     for l in lines:
-        if not l or l.startswith(('.', ';')) or l.endswith(':'):
+        if not l or l.startswith(('.', ';')) or l.endswith(':'):  # directives, comments, labels
             continue
         ops[l.split()[0]] += 1
     return ops
 
 
 def main_loop(lines):
-    """(start, end) of the innermost backward branch that holds (nearly) all the loop's multiply-adds."""
-    labels = {l[:-1]: i for i, l in enumerate(lines) if l.endswith(':') and l.startswith('.LBB')}
+    """(start, end) of the innermost loop with the most multiply-adds."""
+    labels = {l.split(':')[0]: i for i, l in enumerate(lines) if l.startswith('.LBB') and ':' in l}   # (loop headers carry a trailing comment)
     spans = []
     for i, l in enumerate(lines):
         if l.startswith('s_cbranch') or l.startswith('s_branch'):
             tgt = l.split()[-1]
             if tgt in labels and labels[tgt] < i:
                 spans.append((labels[tgt], i, sum(1 for x in lines[labels[tgt]:i] if x.startswith('v_mad_u64_u32'))))
-    top = max(m for _, _, m in spans)
-    a, b, _ = min((s for s in spans if s[2] >= 0.95 * top), key=lambda s: s[1] - s[0])
+    # the innermost loop (no other loop nested in it) with the most multiply-adds: the per-digit (or per-pair-of-digits) loop,
+    # not an outer loop that also holds peeled first / last iterations
+    inner = [s for s in spans if not any(o is not s and s[0] <= o[0] and o[1] <= s[1] for o in spans)]
+    a, b, _ = max(inner, key=lambda s: s[2])
     return a, b
 
 
@@ -72,7 +74,13 @@ def report(argv):
         ("_Z20ntt_rows8_fwd_kernelILb1ELi0EEv7NttArgs", "ntt_rows8_fwd_kernel<SP,0>: stand-alone forward row pass", 32, 0, 8, False),
         ("_Z20ntt_rows8_inv_kernelILb1ELb0ELb0EEv7NttArgs", "ntt_rows8_inv_kernel<SP>: inverse row pass", 32, 0, 0, False),
         ("_Z15ntt_cols_kernelILb1ELb1ELi8EEv7NttArgs", "ntt_cols_kernel<SP,inv,8>: inverse column pass + N^-1 scaling", 64, 16, 16, False),
-        ("_Z23relin_rows8p_mac_kernelILb1EEv9RelinArgs", "relin_rows8p_mac_kernel<SP>: one digit of the j-loop (row pass + 16 key MACs)", 32, 16, 0, True),
+        ("_Z23relin_rows8p_mac_kernelILb1EEv9RelinArgs", "relin_rows8p_mac_kernel<SP> (A/B, rounds 1-2): one digit of the j-loop (row pass + 16 Montgomery MACs)", 32, 16, 0, True),
+        # round 3 default: two digits side by side, 4 elements per thread; a key MAC is 6 multiply-adds into carry-free sums plus 5
+        # instructions per element and digit for the 3 x 22-bit operand split, (6 * 16 + 5 * 8) / 16 = 8.5 per MAC against 16
+        ("_Z22relin_rows4_mac_kernelILb1EEv9RelinArgs", "relin_rows4_mac_kernel<SP>: one PAIR of digits of the j-loop (2 row passes of 4 elements + 16 unreduced MACs)", 32, 16, 0, True),
+        # the rotation pipeline (C4) beside the column passes above
+        ("_Z20ntt_rows8_fwd_kernelILb1ELi4EEv7NttArgs", "ntt_rows8_fwd_kernel<SP,4>: row pass + key product of the normal limbs + mod-down tail (2 multiplies per element)", 32, 16, 8, False),
+        ("_Z24rot_special_rows8_kernelILb1EEv9RotSpArgs", "rot_special_rows8_kernel<SP>: forward row pass + 2 key products + 2 inverse row passes", 96, 16, 0, False),
     ]
     # the generic-prime instantiations (any odd p < 2^62: what a drop-in caller's own table runs): ideal = 23 per butterfly
     # (16-instruction word-serial Montgomery, modarith.h:mont_generic, + 7), 21 per key MAC / scaling multiply

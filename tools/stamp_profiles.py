@@ -15,11 +15,11 @@ import isa_budget  # noqa: E402
 
 # dominant kernel(s) per workload: (symbol, main loop only?, relative weight = threads x launches of that kernel per unit)
 DOMINANT = {
-    "c3": [("_Z23relin_rows8p_mac_kernelILb1EEv9RelinArgs", True, 1)],
-    "c5": [("_Z23relin_rows8p_mac_kernelILb1EEv9RelinArgs", True, 1)],
+    "c3": [("_Z22relin_rows4_mac_kernelILb1EEv9RelinArgs", True, 1)],
+    "c5": [("_Z22relin_rows4_mac_kernelILb1EEv9RelinArgs", True, 1)],
     "ntt": [("_Z15ntt_cols_kernelILb1ELb0ELi8EEv7NttArgs", False, 16), ("_Z20ntt_rows8_fwd_kernelILb1ELi0EEv7NttArgs", False, 32)],
     "c2": [("_Z22ntt_onepass_fwd_kernelILb1ELi6EEv7NttArgsjj", True, 1)],
-    "c4": [("_Z12bconv_kernelILb1ELb1EEv9BconvArgs", False, 1)],
+    "c4": [("_Z20ntt_rows8_fwd_kernelILb1ELi4EEv7NttArgs", False, 1)],
 }
 
 
