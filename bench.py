@@ -318,6 +318,8 @@ class Setup:
             ctx.set_tuning(fhe_amd.hip.TUNE_NTT_CHUNK, ntt_chunk)
         if not onepass:
             ctx.set_tuning(fhe_amd.hip.TUNE_ONEPASS, 0)
+        if os.environ.get("FHE_BENCH_BCONV"):          # A/B switch of the base-conversion kernel (tools only)
+            ctx.set_tuning(fhe_amd.hip.TUNE_BCONV, int(os.environ["FHE_BENCH_BCONV"]))
         if os.environ.get("FHE_BENCH_RELIN_KERNEL"):   # A/B switch of the digit key-switch kernel (tools only)
             ctx.set_tuning(fhe_amd.hip.TUNE_RELIN_KERNEL, int(os.environ["FHE_BENCH_RELIN_KERNEL"]))
         if ntt_streams != 2:
