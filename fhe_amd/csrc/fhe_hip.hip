@@ -297,7 +297,7 @@ int launch_rows(fhe_hip_ctx *c, const NttArgs &a, u32 nl, u32 batch) {
     if (a.epi == 1) { LAUNCH(c, "ntt_fwd_rows_rescale", (ntt_rows8_fwd_kernel<SP, 1>), grid, block, a); return FHE_HIP_OK; }
     if (a.epi == 2) { LAUNCH(c, "ntt_fwd_rows_moddown", (ntt_rows8_fwd_kernel<SP, 2>), grid, block, a); return FHE_HIP_OK; }
     if (a.epi == 3) { LAUNCH(c, "ntt_fwd_rows_encrypt", (ntt_rows8_fwd_kernel<SP, 3>), grid, block, a); return FHE_HIP_OK; }
-    if (a.epi == 4) { LAUNCH(c, "ntt_fwd_rows_rotdown", (ntt_rows8_fwd_kernel<SP, 4>), grid, block, a); return FHE_HIP_OK; }
+    if (a.epi == 4) { LAUNCH(c, "ntt_fwd_rows_rotdown", (ntt_rows8_fwd_kernel<SP, 4>), dim3(R / rows, batch, nl), block, a); return FHE_HIP_OK; }  // limb slowest (kernel comment)
     LAUNCH(c, "ntt_fwd_rows", (ntt_rows8_fwd_kernel<SP, 0>), grid, block, a);
   } else {
     if (a.pre_a && a.perm) FAIL(c, FHE_HIP_ERR_ARG, "internal: inverse row pass with both a gather and a pre-multiply");
@@ -712,7 +712,7 @@ int dev_rotate_to(fhe_hip_ctx *c, u64 galois, u64 *out, const u64 *in, u32 Li, u
   ra.tw_fwd = c->d_tw_fwd; ra.tw_inv = c->d_tw_inv; ra.primes = c->d_primes;
   ra.first_mod = c->L; ra.mmap = nullptr; ra.first_limb = 0; ra.logN = c->logN; ra.logR = c->logR;
   const u32 R = 1u << c->logR, rows = R < 8 ? R : 8;
-  LAUNCH_SP(c, "rot_special_rows", rot_special_rows8_kernel, dim3(R / rows, K, batch), dim3(32 * rows), ra);
+  LAUNCH_SP(c, "rot_special_rows", rot_special_rows8_kernel, dim3(R / rows, batch, K), dim3(32 * rows), ra);
   // from here on the two halves are 2*batch entries of K special limbs: column pass of their inverse NTTs (output = mod-down digits)
   NttPlan pc{E, E, c->d_iota + c->L, 1, K, K, K, 2 * batch, (u64)K * N, (u64)K * N};
   pc.cols_only = true; pc.inv_scale = c->d_moddown_scale_m;
@@ -763,7 +763,7 @@ int dev_rotate_non_ntt(fhe_hip_ctx *c, u64 galois, u64 *ct, u32 Li, u32 batch) {
   ra.tw_fwd = c->d_tw_fwd; ra.tw_inv = c->d_tw_inv; ra.primes = c->d_primes;
   ra.first_mod = 0; ra.mmap = rotmap; ra.first_limb = 0; ra.logN = c->logN; ra.logR = c->logR;
   const u32 R = 1u << c->logR, rows = R < 8 ? R : 8;
-  LAUNCH_SP(c, "rot_special_rows", rot_special_rows8_kernel, dim3(R / rows, nl, batch), dim3(32 * rows), ra);
+  LAUNCH_SP(c, "rot_special_rows", rot_special_rows8_kernel, dim3(R / rows, batch, nl), dim3(32 * rows), ra);
   // the two halves are now 2*batch entries of Li+K limbs: column pass of their inverse NTTs
   NttPlan pc{E, E, rotmap, 1, nl, nl, nl, 2 * batch, (u64)nl * N, (u64)nl * N};
   pc.cols_only = true;

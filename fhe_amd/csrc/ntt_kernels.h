@@ -180,7 +180,10 @@ __global__ __launch_bounds__(256) void ntt_rows8_fwd_kernel(NttArgs a) {
   __shared__ __attribute__((aligned(16))) u64 lds[8 * ROW8_LDS];
   const u32 tid = threadIdx.x, rloc = tid >> 5, t = tid & 31;
   const u32 row = blockIdx.x * (blockDim.x >> 5) + rloc;  // 8 rows per workgroup (R < 8: all R rows, 32 * R threads)
-  const u32 l = blockIdx.y + a.l0, b = blockIdx.z;
+  // EPI == 4: grid = (row blocks, batch entries, limbs), the limb slowest: every entry of the batch reads the same two key limbs and
+  // the same galois index table, which then stay in L2 across the batch, and the two halves of a ciphertext (adjacent entries, same
+  // XCD) share the gathered galois(ax) (profiles/r03: 11.0 GB crossed the L2 boundary per launch with the limb in grid y)
+  const u32 l = (EPI == 4 ? blockIdx.z : blockIdx.y) + a.l0, b = EPI == 4 ? blockIdx.y : blockIdx.z;
   const u32 m = limb_modulus(a, l);
   const PrimeC P = a.primes[m];
   const u64 N = 1ull << a.logN;
@@ -399,12 +402,14 @@ __global__ __launch_bounds__(256) void rot_special_rows8_kernel(RotSpArgs a) {
   __shared__ __attribute__((aligned(16))) u64 lds[8 * ROW8_LDS];
   const u32 tid = threadIdx.x, rloc = tid >> 5, t = tid & 31;
   const u32 row = blockIdx.x * (blockDim.x >> 5) + rloc;  // 8 rows per workgroup (R < 8: all R rows, 32 * R threads)
-  const u32 m = a.mmap ? a.mmap[blockIdx.y] : a.first_mod + blockIdx.y, b = blockIdx.z;
+  // grid = (row blocks, batch entries, limbs): the limb slowest, so that its two key limbs stay in L2 across the batch
+  const u32 ly = blockIdx.z, b = blockIdx.y;
+  const u32 m = a.mmap ? a.mmap[ly] : a.first_mod + ly;
   const PrimeC P = a.primes[m];
   const u64 N = 1ull << a.logN;
   const u64 *__restrict__ twf = a.tw_fwd + (u64)m * N;
   const u64 *__restrict__ twi = a.tw_inv + (u64)m * N;
-  const u64 off = (u64)b * a.estride + (u64)(a.first_limb + blockIdx.y) * N + (u64)row * 256;
+  const u64 off = (u64)b * a.estride + (u64)(a.first_limb + ly) * N + (u64)row * 256;
   u64 *L = lds + rloc * ROW8_LDS;
   const u32 baseA = (1u << a.logR) + row;
   const u32 c = t >> 2, r = t & 3, p0 = row8_pos(8 * t);
