@@ -1,4 +1,5 @@
-"""Randomised soak of the C-ABI against the CPU oracle (many shapes): tools/gpu_soak.py [seconds] [seed] [logN_lo] [logN_hi] [generic] [Lmax].
+"""Randomised soak of the C-ABI against the CPU oracle (many shapes): tools/gpu_soak.py [seconds] [seed] [logN_lo] [logN_hi] [generic] [Lmax] [bconv].
+`bconv` = FHE_HIP_TUNE_BCONV for every context (2: base conversions on the matrix cores at every shape that allows it; default 0 picks by size).
 `generic` = 1 alternates the repository's prime table with primes that are not 1 mod 2^32 (generic Montgomery kernels).
 Not part of the test suite (run time); every mismatch prints the configuration and exits non-zero."""
 import sys, time
@@ -16,6 +17,7 @@ lo = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 hi = int(sys.argv[4]) if len(sys.argv) > 4 else 13
 generic = len(sys.argv) > 5 and sys.argv[5] == "1"
 Lmax = int(sys.argv[6]) if len(sys.argv) > 6 else 8
+bconv = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 
 
 def generic_primes(logN, count):
@@ -42,6 +44,8 @@ while time.time() < t_end:
     pr, ps = generic_primes(logN, L + K) if (generic and n_cfg % 2) else orc.gen_primes(logN, L + K)
     o = orc.Oracle(logN, L, K, pr, ps)
     g = fhe_amd.HipContext(logN, L, K, pr, ps)
+    if bconv:
+        g.set_tuning(fhe_amd.hip.TUNE_BCONV, bconv)
     N = o.N
     cfg = dict(logN=logN, L=L, K=K, Li=Li, B=B, generic=bool(generic and n_cfg % 2))
     def uni(idx):
