@@ -136,6 +136,16 @@ __device__ __forceinline__ void fwd_phase_ua(u64 (&e)[1 << LK], TwPtr tw, const 
   }
 }
 
+// Last stage of an inverse transform with the scaling folded in (N^-1, or the factor a consumer wants in its place): the stage's single
+// twiddle W becomes W*s once per thread, X' = (X + Y)*s and Y' = (X - Y)*(W*s), canonical.  One modular multiplication per element
+// instead of the butterfly's one per pair plus one per element for the scaling: half a multiplication per element saved.
+template <bool SP>
+__device__ __forceinline__ void gs_bfly_scaled(u64 &X, u64 &Y, u64 s_m, u64 Ws_m, const PrimeC &P) {
+  const u64 sum = X + Y;               // < 4p
+  const u64 dif = X - Y + P.twop;      // (0, 4p)
+  X = csub(mont_mul<SP>(s_m, sum, P), P.p);
+  Y = csub(mont_mul<SP>(Ws_m, dif, P), P.p);
+}
 template <bool SP, int LK, typename TwPtr>
 __device__ __forceinline__ void inv_phase(u64 (&e)[1 << LK], TwPtr tw, u32 base, const PrimeC &P) {
 #pragma unroll
@@ -164,6 +174,37 @@ __device__ __forceinline__ void inv_phase_w(u64 (&e)[1 << LK], const u64 (&w)[(1
 #pragma unroll
       for (int j = 0; j < half; ++j) gs_bfly<SP>(e[kk * 2 * half + j], e[kk * 2 * half + j + half], w[(1 << q) - 1 + kk], P);
   }
+}
+// inv_phase / inv_phase_w whose last stage (q == 0, twiddle tw[base] / w[0]) is the transform's last: outputs scaled and canonical
+template <bool SP, int LK, typename TwPtr>
+__device__ __forceinline__ void inv_phase_final(u64 (&e)[1 << LK], TwPtr tw, u32 base, const PrimeC &P, u64 s_m) {
+#pragma unroll
+  for (int q = LK - 1; q >= 1; --q) {
+    const int half = 1 << (LK - 1 - q);
+#pragma unroll
+    for (int kk = 0; kk < (1 << q); ++kk) {
+      const u64 W = tw[(base << q) + kk];
+#pragma unroll
+      for (int j = 0; j < half; ++j) gs_bfly<SP>(e[kk * 2 * half + j], e[kk * 2 * half + j + half], W, P);
+    }
+  }
+  const u64 Ws = csub(mont_mul<SP>(tw[base], s_m, P), P.p);
+#pragma unroll
+  for (int j = 0; j < (1 << (LK - 1)); ++j) gs_bfly_scaled<SP>(e[j], e[j + (1 << (LK - 1))], s_m, Ws, P);
+}
+template <bool SP, int LK>
+__device__ __forceinline__ void inv_phase_w_final(u64 (&e)[1 << LK], const u64 (&w)[(1 << LK) - 1], const PrimeC &P, u64 s_m) {
+#pragma unroll
+  for (int q = LK - 1; q >= 1; --q) {
+    const int half = 1 << (LK - 1 - q);
+#pragma unroll
+    for (int kk = 0; kk < (1 << q); ++kk)
+#pragma unroll
+      for (int j = 0; j < half; ++j) gs_bfly<SP>(e[kk * 2 * half + j], e[kk * 2 * half + j + half], w[(1 << q) - 1 + kk], P);
+  }
+  const u64 Ws = csub(mont_mul<SP>(w[0], s_m, P), P.p);
+#pragma unroll
+  for (int j = 0; j < (1 << (LK - 1)); ++j) gs_bfly_scaled<SP>(e[j], e[j + (1 << (LK - 1))], s_m, Ws, P);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -553,12 +594,13 @@ __global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs
       u64 e[1 << LB];
 #pragma unroll
       for (int k = 0; k < (1 << LB); ++k) { e[k] = s[(u64)((u << LB) + k) * 256 + c]; DBG_RANGE(e[k], P.twop, 8); }
-      inv_phase<SP, LB>(e, tw, (1u << LA) + u, P);
+      if constexpr (LA > 0) inv_phase<SP, LB>(e, tw, (1u << LA) + u, P);
+      else inv_phase_final<SP, LB>(e, tw, 1u + u, P, nscale);   // (u == 0: R <= 16 rows are one register phase)
 #pragma unroll
       for (int k = 0; k < (1 << LB); ++k) {
         const u32 row = (u << LB) + k;
         if constexpr (LA > 0) lds[row * CS + c] = e[k];
-        else { const u64 r = csub(mont_mul<SP>(nscale, e[k], P), P.p); DBG_RANGE(r, P.p, 9); d[(u64)row * 256 + c] = r; }
+        else { DBG_RANGE(e[k], P.p, 9); d[(u64)row * 256 + c] = e[k]; }
       }
     }
     if constexpr (LA > 0) {
@@ -570,9 +612,9 @@ __global__ __launch_bounds__(ColCfg<LOGR>::THREADS) void ntt_cols_kernel(NttArgs
         u64 e[1 << LA];
 #pragma unroll
         for (int k = 0; k < (1 << LA); ++k) e[k] = lds[(g + G * k) * CS + c];
-        inv_phase<SP, LA>(e, tw, 1u, P);
+        inv_phase_final<SP, LA>(e, tw, 1u, P, nscale);
 #pragma unroll
-        for (int k = 0; k < (1 << LA); ++k) { const u64 r = csub(mont_mul<SP>(nscale, e[k], P), P.p); DBG_RANGE(r, P.p, 9); d[(u64)(g + G * k) * 256 + c] = r; }
+        for (int k = 0; k < (1 << LA); ++k) { DBG_RANGE(e[k], P.p, 9); d[(u64)(g + G * k) * 256 + c] = e[k]; }
       }
     }
   }
@@ -1272,7 +1314,8 @@ __global__ __launch_bounds__(OneCfg<LOGR>::T) void ntt_onepass_inv_kernel(NttArg
       u64 e[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) e[k] = lds[tile_pos((u << LB) + k, c)];
-      inv_phase_w<SP, LB>(e, wcol, P);
+      if constexpr (LA > 0) inv_phase_w<SP, LB>(e, wcol, P);
+      else inv_phase_w_final<SP, LB>(e, wcol, P, nscale);
       if constexpr (LA > 0) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) lds[tile_pos((u << LB) + k, c)] = e[k];
@@ -1284,17 +1327,17 @@ __global__ __launch_bounds__(OneCfg<LOGR>::T) void ntt_onepass_inv_kernel(NttArg
           u64 f[1 << LA];
 #pragma unroll
           for (int k = 0; k < (1 << LA); ++k) f[k] = lds[tile_pos(g + G * k, cc)];
-          inv_phase<SP, LA>(f, twc, 1u, P);
+          inv_phase_final<SP, LA>(f, twc, 1u, P, nscale);
 #pragma unroll
           for (int k = 0; k < (1 << LA); ++k) {
-            const u64 v = csub(mont_mul<SP>(nscale, f[k], P), P.p);
+            const u64 v = f[k];
             DBG_RANGE(v, P.p, 9);
             (d + (u64)(rep * (T / 256) + G * k) * 256)[tid] = v;
           }
         }
       } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { const u64 v = csub(mont_mul<SP>(nscale, e[k], P), P.p); DBG_RANGE(v, P.p, 9); (d + (u64)k * 256)[tid] = v; }
+        for (int k = 0; k < 16; ++k) { DBG_RANGE(e[k], P.p, 9); (d + (u64)k * 256)[tid] = e[k]; }
       }
     }
     if (next >= total) break;
