@@ -73,7 +73,7 @@ def report(argv):
         ("_Z15ntt_cols_kernelILb1ELb0ELi8EEv7NttArgs", "ntt_cols_kernel<SP,fwd,8>: stand-alone and relinearisation column pass", 64, 0, 0, False),
         ("_Z20ntt_rows8_fwd_kernelILb1ELi0EEv7NttArgs", "ntt_rows8_fwd_kernel<SP,0>: stand-alone forward row pass", 32, 0, 8, False),
         ("_Z20ntt_rows8_inv_kernelILb1ELb0ELb0EEv7NttArgs", "ntt_rows8_inv_kernel<SP>: inverse row pass", 32, 0, 0, False),
-        ("_Z15ntt_cols_kernelILb1ELb1ELi8EEv7NttArgs", "ntt_cols_kernel<SP,inv,8>: inverse column pass + N^-1 scaling", 64, 16, 16, False),
+        ("_Z15ntt_cols_kernelILb1ELb1ELi8EEv7NttArgs", "ntt_cols_kernel<SP,inv,8>: inverse column pass, scaling folded into the last stage (8 extra multiplies)", 64, 8, 16, False),
         ("_Z23relin_rows8p_mac_kernelILb1EEv9RelinArgs", "relin_rows8p_mac_kernel<SP> (A/B, rounds 1-2): one digit of the j-loop (row pass + 16 Montgomery MACs)", 32, 16, 0, True),
         # round 3 default: two digits side by side, 4 elements per thread; a key MAC is 6 multiply-adds into carry-free sums plus 5
         # instructions per element and digit for the 3 x 22-bit operand split, (6 * 16 + 5 * 8) / 16 = 8.5 per MAC against 16
