@@ -8,7 +8,8 @@
 // not on the north star's hot path: the kernels are plain (LDS-bound), correct and measured, not tuned.
 #pragma once
 #include "modarith.h"
-#include "ntt_kernels.h"   // canon4
+#include "ntt_kernels.h"        // canon4
+#include "pointwise_kernels.h"  // bconv_fold
 
 typedef double2 cplx;
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
@@ -143,48 +144,134 @@ __global__ __launch_bounds__(256) void enc_round_kernel(u64 *msg, const cplx *w,
 struct DecLiftArgs {
   cplx *w; const u64 *msg;
   const PrimeC *primes;
-  const u64 *qmod_m;     // [L][L]: (q_j mod q_k) at [k][j], Montgomery form under q_k
+  const u64 *prod_m;     // [L][L]: row k: (q_0 .. q_{j-1} mod q_k) * 2^128 mod q_k, j < k
   const u64 *ginv_m;     // [L]: (q_0 .. q_{k-1})^-1 mod q_k, Montgomery form (entry 0 unused)
   const u64 *half;       // [n]: mixed-radix digits of floor(Q_n / 2)
   const double *qd;      // [L]: q_k as double
   u32 n, L; u64 N; double inv_scale;
 };
 constexpr int DEC_MAX_LIMBS = 64;
+constexpr int DEC_THREADS = 128;
+// Garner's mixed-radix lift, digit k: v_k = (x_k - sum_{j<k} v_j M_{j,k}) * (q_0 .. q_{k-1})^-1 mod q_k with M_{j,k} = q_0 .. q_{j-1} mod q_k.
+// The sum is accumulated without carries like the base conversion's (pointwise_kernels.h: bconv_fold): a digit is kept in LDS as
+// three 21-bit limbs, M (uniform, from the scalar cache, stored times 2^128) gives its two words, six v_mad_u64_u32 per term into six
+// 64-bit sums (room for 2^6 terms: DEC_MAX_LIMBS), one fold per digit.  Round 3 first had a Horner form with a modular multiplication per
+// term and the digits in a dynamically indexed private array (2.64 ms per 64 polynomials of 30 limbs at N = 2^16).
 template <bool SP>
-__global__ __launch_bounds__(256) void dec_lift_kernel(DecLiftArgs a) {
-  const u64 d = (u64)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(DEC_THREADS) void dec_lift_kernel(DecLiftArgs a) {
+  extern __shared__ __attribute__((aligned(16))) u32 dec_vl[];   // [n][n] Garner constants (u64), then [3][n][DEC_THREADS]: 21-bit limbs of the digits
+  const u32 tid = threadIdx.x, n = a.n;
+  u64 *Ml = reinterpret_cast<u64 *>(dec_vl);   // a scalar load per term, waited for where it is used, costs its latency 435 times per coefficient
+  for (u32 i = tid; i < n * n; i += DEC_THREADS) Ml[i] = a.prod_m[(u64)(i / n) * a.L + i % n];
+  __syncthreads();
+  const u64 d = (u64)blockIdx.x * DEC_THREADS + tid;
   const u64 b = blockIdx.y;
-  u64 v[DEC_MAX_LIMBS];
-  const u32 n = a.n;
+  u32 *l0 = dec_vl + 2 * n * n + tid, *l1 = l0 + n * DEC_THREADS, *l2 = l1 + n * DEC_THREADS;
+  auto digit = [&](u32 k) { return (u64)l0[k * DEC_THREADS] | ((u64)l1[k * DEC_THREADS] << 21) | ((u64)l2[k * DEC_THREADS] << 42); };
+  auto put = [&](u32 k, u64 v) { l0[k * DEC_THREADS] = (u32)v & 0x1FFFFFu; l1[k * DEC_THREADS] = (u32)(v >> 21) & 0x1FFFFFu; l2[k * DEC_THREADS] = (u32)(v >> 42); };
   for (u32 k = 0; k < n; ++k) {
     const PrimeC P = a.primes[k];
-    const u64 xk = a.msg[(b * n + k) * a.N + d] % P.p;
-    u64 part = 0;  // (v_0 + v_1 q_0 + ... ) mod q_k by Horner from the top digit, in [0, p)
-    for (u32 j = k; j-- > 0;) {
-      const u64 t = csub(mont_mul<SP>(a.qmod_m[(u64)k * a.L + j], part, P), P.p);  // part * q_j mod q_k
-      part = csub(t + canon4(v[j], P), P.p);   // v_j < q_j < 4 q_k (primes of one table lie within a factor 4)
+    u64 xk = a.msg[(b * n + k) * a.N + d];
+    if (xk >= 2 * P.twop) xk %= P.p;   // (out of contract: residues are expected below 4p; kept exact all the same)
+    xk = canon4(xk, P);
+    u64 acc[6] = {0, 0, 0, 0, 0, 0};
+    const u64 *Mk = Ml + k * n;
+#pragma unroll 8
+    for (u32 j = 0; j < k; ++j) {
+      const u64 M = Mk[j];
+      const u32 b0 = (u32)M, b1 = (u32)(M >> 32);
+      const u32 h0 = l0[j * DEC_THREADS], h1 = l1[j * DEC_THREADS], h2 = l2[j * DEC_THREADS];
+      acc[0] = mad_wide(h0, b0, acc[0]); acc[1] = mad_wide(h1, b0, acc[1]); acc[2] = mad_wide(h2, b0, acc[2]);
+      acc[3] = mad_wide(h0, b1, acc[3]); acc[4] = mad_wide(h1, b1, acc[4]); acc[5] = mad_wide(h2, b1, acc[5]);
     }
+    const u64 part = k ? bconv_fold<SP>(acc, P) : 0;   // sum_j v_j M_{j,k} mod q_k, canonical
     const u64 diff = xk >= part ? xk - part : xk + P.p - part;
-    v[k] = k ? csub(mont_mul<SP>(a.ginv_m[k], diff, P), P.p) : diff;
+    put(k, k ? csub(mont_mul<SP>(a.ginv_m[k], diff, P), P.p) : diff);
   }
   // X >= floor(Q/2)?  (lexicographic from the top digit; equal counts as >=, like mpz_cmp(..) >= 0)
   bool upper = true;
   for (u32 k = n; k-- > 0;) {
-    const u64 h = a.half[k];
-    if (v[k] != h) { upper = v[k] > h; break; }
+    const u64 h = a.half[k], v = digit(k);
+    if (v != h) { upper = v > h; break; }
   }
-  if (upper) {  // digits of Q - X = (Q - 1 - X) + 1: (q_k - 1 - v_k) needs no borrow, then add one with carry
+  // digits of Q - X = (Q - 1 - X) + 1: (q_k - 1 - v_k) needs no borrow, then add one with carry; Horner from the top digit:
+  // ((v_{n-1} q_{n-2} + v_{n-2}) q_{n-3} + ...) q_0 + v_0 needs the negated digits from the bottom up first
+  if (upper) {
     bool carry = true;
     for (u32 k = 0; k < n; ++k) {
       const u64 q = a.primes[k].p;
-      u64 t = q - 1 - v[k];
+      u64 t = q - 1 - digit(k);
       if (carry) { t += 1; carry = (t == q); if (carry) t = 0; }
-      v[k] = t;
+      put(k, t);
     }
   }
   double val = 0.0;
-  for (u32 k = n; k-- > 0;) val = val * a.qd[k] + (double)v[k];   // ((v_{n-1} q_{n-2} + v_{n-2}) q_{n-3} + ...) q_0 + v_0
+  for (u32 k = n; k-- > 0;) val = val * a.qd[k] + (double)digit(k);
   // (digit k is multiplied by q_{k-1} .. q_0: the factor applied when stepping from digit k to digit k-1 is q_{k-1})
+  a.w[b * a.N + d] = make_double2((upper ? -val : val) * a.inv_scale, 0.0);
+}
+
+// The same lift for up to DEC_REG_LIMBS limbs with the digits' limbs in REGISTERS: every loop is unrolled to the bound with uniform guards, so
+// the digit arrays are indexed statically and the Garner constants come through merged scalar loads; no LDS, no dependent LDS latency under the
+// multiply-adds (the LDS form above runs 1.5 waves per SIMD and waits for its own reads).
+constexpr int DEC_REG_LIMBS = 32;
+template <bool SP>
+__global__ __launch_bounds__(256) void dec_lift_reg_kernel(DecLiftArgs a) {
+  const u32 n = a.n;
+  const u64 d = (u64)blockIdx.x * 256 + threadIdx.x;
+  const u64 b = blockIdx.y;
+  u32 h0[DEC_REG_LIMBS], h1[DEC_REG_LIMBS], h2[DEC_REG_LIMBS];
+#pragma unroll
+  for (int k = 0; k < DEC_REG_LIMBS; ++k) { h0[k] = 0; h1[k] = 0; h2[k] = 0; }
+#pragma unroll
+  for (int k = 0; k < DEC_REG_LIMBS; ++k) {
+    if ((u32)k < n) {
+      const PrimeC P = a.primes[k];
+      u64 xk = a.msg[(b * n + k) * a.N + d];
+      if (xk >= 2 * P.twop) xk %= P.p;   // (out of contract: residues are expected below 4p; kept exact all the same)
+      xk = canon4(xk, P);
+      u64 acc[6] = {0, 0, 0, 0, 0, 0};
+      const u64 *Mk = a.prod_m + (u64)k * a.L;
+#pragma unroll
+      for (int j = 0; j < k; ++j) {
+        const u64 M = Mk[j];
+        const u32 b0 = (u32)M, b1 = (u32)(M >> 32);
+        acc[0] = mad_wide(h0[j], b0, acc[0]); acc[1] = mad_wide(h1[j], b0, acc[1]); acc[2] = mad_wide(h2[j], b0, acc[2]);
+        acc[3] = mad_wide(h0[j], b1, acc[3]); acc[4] = mad_wide(h1[j], b1, acc[4]); acc[5] = mad_wide(h2[j], b1, acc[5]);
+      }
+      const u64 part = k ? bconv_fold<SP>(acc, P) : 0;
+      const u64 diff = xk >= part ? xk - part : xk + P.p - part;
+      const u64 v = k ? csub(mont_mul<SP>(a.ginv_m[k], diff, P), P.p) : diff;
+      h0[k] = (u32)v & 0x1FFFFFu; h1[k] = (u32)(v >> 21) & 0x1FFFFFu; h2[k] = (u32)(v >> 42);
+    }
+  }
+  auto digit = [&](int k) { return (u64)h0[k] | ((u64)h1[k] << 21) | ((u64)h2[k] << 42); };
+  // X >= floor(Q/2)?  (lexicographic from the top digit; equal counts as >=): first differing digit from the top decides
+  bool upper = true, decided = false;
+#pragma unroll
+  for (int k = DEC_REG_LIMBS - 1; k >= 0; --k) {
+    if ((u32)k < n) {
+      const u64 h = a.half[k], v = digit(k);
+      if (!decided && v != h) { upper = v > h; decided = true; }
+    }
+  }
+  // negated digits (Q - X) from the bottom up, then Horner from the top
+  u64 vv[DEC_REG_LIMBS];
+  bool carry = true;
+#pragma unroll
+  for (int k = 0; k < DEC_REG_LIMBS; ++k) {
+    vv[k] = 0;
+    if ((u32)k < n) {
+      const u64 v = digit(k), q = a.primes[k].p;
+      u64 t = q - 1 - v;
+      if (carry) { t += 1; carry = (t == q); if (carry) t = 0; }
+      vv[k] = upper ? t : v;
+    }
+  }
+  double val = 0.0;
+#pragma unroll
+  for (int k = DEC_REG_LIMBS - 1; k >= 0; --k)
+    if ((u32)k < n) val = val * a.qd[k] + (double)vv[k];
   a.w[b * a.N + d] = make_double2((upper ? -val : val) * a.inv_scale, 0.0);
 }
 

@@ -80,7 +80,8 @@ struct fhe_hip_ctx {
   // encoder (fhe_hip_encode / _decode), built on first use: psi^brv(i) as complex doubles, the generator-3 slot index map, and the
   // Garner constants of the CRT lift over the normal primes
   cplx *d_enc_roots = nullptr; u32 *d_enc_map = nullptr;
-  u64 *d_enc_qmod_m = nullptr, *d_enc_ginv_m = nullptr; double *d_enc_qd = nullptr;
+  u64 *d_enc_prod_m = nullptr, *d_enc_ginv_m = nullptr; double *d_enc_qd = nullptr;
+  bool dec_attr_set = false;
   std::map<u32, u64 *> enc_half;   // limb count n -> mixed-radix digits of floor(q_0 .. q_{n-1} / 2)
   // keys
   u64 *d_mk_beta = nullptr, *d_mk_alpha = nullptr;  // [L][L][N] Montgomery form
@@ -978,7 +979,7 @@ void fhe_hip_ctx_destroy(fhe_hip_ctx *c) {
   for (auto &kv : c->mixed_keys) { hipFree(kv.second.beta_m); hipFree(kv.second.alpha_m); }
   for (auto &kv : c->galois_perm) hipFree(kv.second);
   for (auto &kv : c->enc_half) hipFree(kv.second);
-  { void *enc[] = {c->d_enc_roots, c->d_enc_map, c->d_enc_qmod_m, c->d_enc_ginv_m, c->d_enc_qd}; for (void *p : enc) if (p) hipFree(p); }
+  { void *enc[] = {c->d_enc_roots, c->d_enc_map, c->d_enc_prod_m, c->d_enc_ginv_m, c->d_enc_qd}; for (void *p : enc) if (p) hipFree(p); }
   for (void *p : c->ws) if (p) hipFree(p);
   for (void *p : c->stage) if (p) hipFree(p);
   if (c->d_idx) hipFree(c->d_idx);
@@ -1788,17 +1789,17 @@ int ensure_encoder_tables(fhe_hip_ctx *c) {
     map[N / 2 + i] = (u32)h_brv((2 * N - pos - 1) >> 1, logN);
     pos = (pos * 3) & (2 * N - 1);
   }
-  std::vector<u64> qmod((size_t)L * L, 0), ginv(L, 0);
+  std::vector<u64> prodm((size_t)L * L, 0), ginv(L, 0);   // Garner constants: (q_0 .. q_{j-1} mod q_k) * 2^128 at [k][j], (q_0 .. q_{k-1})^-1 mod q_k
   std::vector<double> qd(L);
   const std::vector<u64> &P = c->primes;
   for (u32 k = 0; k < L; ++k) {
     qd[k] = (double)P[k];
     u64 prod = 1;
-    for (u32 j = 0; j < k; ++j) { qmod[(size_t)k * L + j] = h_to_mont(P[j] % P[k], P[k]); prod = h_mulmod(prod, P[j] % P[k], P[k]); }
+    for (u32 j = 0; j < k; ++j) { prodm[(size_t)k * L + j] = h_to_mont(h_to_mont(prod, P[k]), P[k]); prod = h_mulmod(prod, P[j] % P[k], P[k]); }
     if (k) ginv[k] = h_to_mont(h_invmod(prod, P[k]), P[k]);
   }
   int rc;
-  if ((rc = upload(c, &c->d_enc_map, map)) || (rc = upload(c, &c->d_enc_qmod_m, qmod)) || (rc = upload(c, &c->d_enc_ginv_m, ginv)) ||
+  if ((rc = upload(c, &c->d_enc_map, map)) || (rc = upload(c, &c->d_enc_prod_m, prodm)) || (rc = upload(c, &c->d_enc_ginv_m, ginv)) ||
       (rc = upload(c, &c->d_enc_qd, qd)) || (rc = upload(c, &c->d_enc_roots, roots))) return rc;
   return FHE_HIP_OK;
 }
@@ -1895,9 +1896,24 @@ int fhe_hip_decode(fhe_hip_ctx *c, double *slots, const uint64_t *msg, uint32_t 
   TRY(st.in(msg, batch * nlimbs * N * 8, &dmsg));
   TRY(st.out(slots, batch * (N / 2) * sizeof(cplx), &dslots, false));
   DecLiftArgs a;
-  a.w = w; a.msg = dmsg; a.primes = c->d_primes; a.qmod_m = c->d_enc_qmod_m; a.ginv_m = c->d_enc_ginv_m; a.half = half; a.qd = c->d_enc_qd;
+  a.w = w; a.msg = dmsg; a.primes = c->d_primes; a.prod_m = c->d_enc_prod_m; a.ginv_m = c->d_enc_ginv_m; a.half = half; a.qd = c->d_enc_qd;
   a.n = nlimbs; a.L = c->L; a.N = N; a.inv_scale = 1.0 / scale;
-  LAUNCH_SP(c, "dec_lift", dec_lift_kernel, dim3((unsigned)(N / 256), (unsigned)batch), dim3(256), a);
+  if (nlimbs <= DEC_REG_LIMBS) {
+    LAUNCH_SP(c, "dec_lift", dec_lift_reg_kernel, dim3((unsigned)(N / 256), (unsigned)batch), dim3(256), a);
+  } else {
+    const size_t smem = (size_t)nlimbs * nlimbs * 8 + (size_t)3 * nlimbs * DEC_THREADS * sizeof(u32);   // Garner constants + the digits' 21-bit limbs (128 KB at 64 limbs)
+    if (!c->dec_attr_set) {
+      HIPCHK(c, hipFuncSetAttribute((const void *)dec_lift_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(c, hipFuncSetAttribute((const void *)dec_lift_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      c->dec_attr_set = true;
+    }
+    hipEvent_t ev0 = nullptr;
+    if (c->prof && !c->fixed_ws) ev0 = c->chain_valid ? c->chain_ev : prof_event(c);
+    if (c->sp) hipLaunchKernelGGL((dec_lift_kernel<true>), dim3((unsigned)(N / DEC_THREADS), (unsigned)batch), dim3(DEC_THREADS), smem, c->stream, a);
+    else hipLaunchKernelGGL((dec_lift_kernel<false>), dim3((unsigned)(N / DEC_THREADS), (unsigned)batch), dim3(DEC_THREADS), smem, c->stream, a);
+    if (c->prof && !c->fixed_ws) { c->chain_ev = prof_event(c); c->chain_valid = true; prof_entry(c, "dec_lift")->pending.push_back({ev0, c->chain_ev}); }
+    HIPCHK(c, hipGetLastError());
+  }
   TRY((enc_fft<false>(c, w, (u32)batch)));
   LAUNCH(c, "dec_pick", dec_pick_kernel, dim3((unsigned)((N / 2 + 255) / 256), (unsigned)batch), dim3(256), (cplx *)dslots, (const cplx *)w, (const u32 *)c->d_enc_map, N);
   return st.finish();

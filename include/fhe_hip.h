@@ -188,7 +188,8 @@ int fhe_hip_mul_relin_rescale_noalloc(fhe_hip_ctx *ctx, uint64_t *out, const uin
  * coefficient = trunc(Re(iFFT(slots through the generator-3 index map))[d] * scale / N) mod P[l], non-negative remainder
  * (mpz_set_d + mpz_mod_ui).  Floating point (complex double, like the reference): results agree with a CPU run to rounding.
  * Encoder::decode (encoder.hpp:39-45, encoder.cpp:159-200): msg = [batch][nlimbs][N] power basis -> slots = [batch][N/2] complex
- * doubles: CRT lift to [0, Q), centred around Q/2, divided by scale, FFT, slots picked through the index map. */
+ * doubles: CRT lift to [0, Q), centred around Q/2, divided by scale, FFT, slots picked through the index map.  Residues are expected
+ * canonical (any value below 4p costs nothing extra; larger words are reduced exactly on a slow path). */
 int fhe_hip_encode(fhe_hip_ctx *ctx, uint64_t *msg, const double *values, size_t nvals, uint32_t nlimbs, double scale, size_t batch, int mem_kind);
 int fhe_hip_decode(fhe_hip_ctx *ctx, double *slots, const uint64_t *msg, uint32_t nlimbs, double scale, size_t batch, int mem_kind);
 

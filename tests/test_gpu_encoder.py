@@ -21,7 +21,9 @@ def _centred(row, p):
     return np.array([int(v) - p if int(v) > p // 2 else int(v) for v in r], dtype=object)
 
 
-@pytest.mark.parametrize("logN,L,scale_bits,sp", [(10, 3, 30, True), (12, 4, 50, True), (13, 3, 62, True), (11, 3, 40, False)])
+# (L = 30 runs the register-resident Garner lift at its full unrolled depth, L = 35 the LDS form for more than 32 limbs)
+@pytest.mark.parametrize("logN,L,scale_bits,sp", [(10, 3, 30, True), (12, 4, 50, True), (13, 3, 62, True), (11, 3, 40, False),
+                                                  (10, 30, 45, True), (10, 35, 45, True), (10, 33, 50, False)])
 def test_encode_decode_against_the_oracle(logN, L, scale_bits, sp):
     if sp:
         pr, ps = orc.gen_primes(logN, L + 1)
