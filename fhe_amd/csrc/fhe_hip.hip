@@ -225,17 +225,18 @@ inline hipEvent_t prof_event(fhe_hip_ctx *c) {
   return ev;
 }
 
-#define LAUNCH(c, name, kern, grid, block, ...)                                                  \
+#define LAUNCH_SMEM(c, name, kern, grid, block, smem, ...)                                      \
   do {                                                                                           \
     hipEvent_t ev0_ = nullptr;                                                                   \
     if ((c)->prof && !(c)->fixed_ws) ev0_ = (c)->chain_valid ? (c)->chain_ev : prof_event(c);                      \
-    hipLaunchKernelGGL(kern, grid, block, 0, (c)->stream, __VA_ARGS__);                          \
+    hipLaunchKernelGGL(kern, grid, block, smem, (c)->stream, __VA_ARGS__);                       \
     if ((c)->prof && !(c)->fixed_ws) {                                                           \
       (c)->chain_ev = prof_event(c); (c)->chain_valid = true;                                    \
       prof_entry((c), name)->pending.push_back({ev0_, (c)->chain_ev});                           \
     }                                                                                            \
     HIPCHK(c, hipGetLastError());                                                                \
   } while (0)
+#define LAUNCH(c, name, kern, grid, block, ...) LAUNCH_SMEM(c, name, kern, grid, block, 0, __VA_ARGS__)
 
 #define LAUNCH_SP(c, name, kern, grid, block, ...)                                               \
   do {                                                                                           \
@@ -430,15 +431,8 @@ int launch_bconv_mfma(fhe_hip_ctx *c, const char *name, const BconvMfmaArgs &m, 
     HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
-  hipEvent_t ev0 = nullptr;
-  if (c->prof && !c->fixed_ws) ev0 = c->chain_valid ? c->chain_ev : prof_event(c);
-  if (c->sp) hipLaunchKernelGGL((bconv_mfma_kernel<true, NS, PRE>), dim3(grid), dim3(BCONV_MFMA_THREADS), smem, c->stream, m);
-  else hipLaunchKernelGGL((bconv_mfma_kernel<false, NS, PRE>), dim3(grid), dim3(BCONV_MFMA_THREADS), smem, c->stream, m);
-  if (c->prof && !c->fixed_ws) {
-    c->chain_ev = prof_event(c); c->chain_valid = true;
-    prof_entry(c, name)->pending.push_back({ev0, c->chain_ev});
-  }
-  HIPCHK(c, hipGetLastError());
+  if (c->sp) LAUNCH_SMEM(c, name, (bconv_mfma_kernel<true, NS, PRE>), dim3(grid), dim3(BCONV_MFMA_THREADS), smem, m);
+  else LAUNCH_SMEM(c, name, (bconv_mfma_kernel<false, NS, PRE>), dim3(grid), dim3(BCONV_MFMA_THREADS), smem, m);
   return FHE_HIP_OK;
 }
 int try_bconv_mfma(fhe_hip_ctx *c, const char *name, const BconvArgs &a, const u64 *hat_h, u32 table_key, u32 table_ntgt, u32 batch, bool pre, bool *done) {
@@ -1831,17 +1825,9 @@ template <bool INV> int enc_fft(fhe_hip_ctx *c, cplx *w, u32 batch) {
   const size_t smem = (size_t)R * ENC_CT * sizeof(cplx);
   if constexpr (INV) {
     LAUNCH(c, "enc_ifft_rows", (enc_fft_rows_kernel<true>), dim3(R / 2, batch), dim3(256), w, (const cplx *)c->d_enc_roots, c->logN);
-    hipEvent_t ev0_ = nullptr;  // (dynamic LDS: launched by hand, timed like LAUNCH)
-    if (c->prof && !c->fixed_ws) ev0_ = c->chain_valid ? c->chain_ev : prof_event(c);
-    hipLaunchKernelGGL((enc_fft_cols_kernel<true>), dim3(256 / ENC_CT, batch), dim3(256), smem, c->stream, w, (const cplx *)c->d_enc_roots, c->logN);
-    if (c->prof && !c->fixed_ws) { c->chain_ev = prof_event(c); c->chain_valid = true; prof_entry(c, "enc_ifft_cols")->pending.push_back({ev0_, c->chain_ev}); }
-    HIPCHK(c, hipGetLastError());
+    LAUNCH_SMEM(c, "enc_ifft_cols", (enc_fft_cols_kernel<true>), dim3(256 / ENC_CT, batch), dim3(256), smem, w, (const cplx *)c->d_enc_roots, c->logN);
   } else {
-    hipEvent_t ev0_ = nullptr;
-    if (c->prof && !c->fixed_ws) ev0_ = c->chain_valid ? c->chain_ev : prof_event(c);
-    hipLaunchKernelGGL((enc_fft_cols_kernel<false>), dim3(256 / ENC_CT, batch), dim3(256), smem, c->stream, w, (const cplx *)c->d_enc_roots, c->logN);
-    if (c->prof && !c->fixed_ws) { c->chain_ev = prof_event(c); c->chain_valid = true; prof_entry(c, "enc_fft_cols")->pending.push_back({ev0_, c->chain_ev}); }
-    HIPCHK(c, hipGetLastError());
+    LAUNCH_SMEM(c, "enc_fft_cols", (enc_fft_cols_kernel<false>), dim3(256 / ENC_CT, batch), dim3(256), smem, w, (const cplx *)c->d_enc_roots, c->logN);
     LAUNCH(c, "enc_fft_rows", (enc_fft_rows_kernel<false>), dim3(R / 2, batch), dim3(256), w, (const cplx *)c->d_enc_roots, c->logN);
   }
   return FHE_HIP_OK;
@@ -1907,12 +1893,8 @@ int fhe_hip_decode(fhe_hip_ctx *c, double *slots, const uint64_t *msg, uint32_t 
       HIPCHK(c, hipFuncSetAttribute((const void *)dec_lift_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       c->dec_attr_set = true;
     }
-    hipEvent_t ev0 = nullptr;
-    if (c->prof && !c->fixed_ws) ev0 = c->chain_valid ? c->chain_ev : prof_event(c);
-    if (c->sp) hipLaunchKernelGGL((dec_lift_kernel<true>), dim3((unsigned)(N / DEC_THREADS), (unsigned)batch), dim3(DEC_THREADS), smem, c->stream, a);
-    else hipLaunchKernelGGL((dec_lift_kernel<false>), dim3((unsigned)(N / DEC_THREADS), (unsigned)batch), dim3(DEC_THREADS), smem, c->stream, a);
-    if (c->prof && !c->fixed_ws) { c->chain_ev = prof_event(c); c->chain_valid = true; prof_entry(c, "dec_lift")->pending.push_back({ev0, c->chain_ev}); }
-    HIPCHK(c, hipGetLastError());
+    if (c->sp) LAUNCH_SMEM(c, "dec_lift", (dec_lift_kernel<true>), dim3((unsigned)(N / DEC_THREADS), (unsigned)batch), dim3(DEC_THREADS), smem, a);
+    else LAUNCH_SMEM(c, "dec_lift", (dec_lift_kernel<false>), dim3((unsigned)(N / DEC_THREADS), (unsigned)batch), dim3(DEC_THREADS), smem, a);
   }
   TRY((enc_fft<false>(c, w, (u32)batch)));
   LAUNCH(c, "dec_pick", dec_pick_kernel, dim3((unsigned)((N / 2 + 255) / 256), (unsigned)batch), dim3(256), (cplx *)dslots, (const cplx *)w, (const u32 *)c->d_enc_map, N);
