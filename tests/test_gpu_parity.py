@@ -384,6 +384,45 @@ def test_cross_mult_relin_rescale_pipeline(logN, L, K, Li, sp):
     assert np.array_equal(want2, want)
 
 
+@pytest.mark.parametrize("logN,L,K,Li,sp", [(10, 4, 4, 4, True), (11, 5, 1, 3, False), (10, 18, 1, 18, True)])
+def test_digit_key_switch_kernels_agree_and_refuse_each_others_keys(logN, L, K, Li, sp):
+    """FHE_HIP_TUNE_RELIN_KERNEL: the round-3 kernel (unreduced key-MAC accumulators, keys stored times 2^128) and the Montgomery-MAC
+    kernel of rounds 1-2 (keys times 2^64) give the same bits as the oracle for relinearisation and MixedRotKey rotation; a key
+    loaded for one kernel is refused by the other instead of being misread."""
+    o, g = ctx_pair(logN, L, K, sp)
+    sx, ext, pkb, pka, beta, alpha = _keys(o, 150)
+    B = 2
+    c0 = np.stack([np.stack([rand_poly(o, range(Li), 160 + 2 * b), rand_poly(o, range(Li), 161 + 2 * b)]) for b in range(B)])
+    c1 = np.stack([np.stack([rand_poly(o, range(Li), 170 + 2 * b), rand_poly(o, range(Li), 171 + 2 * b)]) for b in range(B)])
+    want = np.stack([np.stack(o.mul_relin_rescale(c0[b, 0], c0[b, 1], c1[b, 0], c1[b, 1], beta, alpha)) for b in range(B)])
+    gal = o.rotation_galois(1)
+    rng = np.random.default_rng(151)
+    uni = lambda idx: np.stack([rng.integers(0, int(o.primes[i]), o.N, dtype=np.uint64) for i in idx])
+    mb = np.stack([uni(list(range(L)) + [L]) for _ in range(L)]); ma = np.stack([uni(list(range(L)) + [L]) for _ in range(L)])
+    want_rot = np.stack([np.stack(o.rotate_mixed(c0[b, 0], c0[b, 1], gal, mb, ma)) for b in range(B)])
+    try:
+        for mode in (0, 1):
+            g.set_tuning(fhe_amd.hip.TUNE_RELIN_KERNEL, mode)
+            g.load_mult_key(dev(beta), dev(alpha))
+            g.load_mixed_rot_key(gal, dev(mb), dev(ma))
+            out = torch.zeros((B, 2, Li - 1, o.N), dtype=torch.int64, device="cuda")
+            g.mul_relin_rescale(out, dev(c0), dev(c1), Li, batch=B)
+            assert np.array_equal(host(out), want), mode
+            d = dev(c0)
+            g.rotate_mixed(gal, d, Li, batch=B)
+            assert np.array_equal(host(d), want_rot), mode
+            # the keys stay in this kernel's form: the other kernel refuses them
+            g.set_tuning(fhe_amd.hip.TUNE_RELIN_KERNEL, 1 - mode)
+            with pytest.raises(fhe_amd.FheHipError) as ei:
+                g.mul_relin_rescale(out, dev(c0), dev(c1), Li, batch=B)
+            assert ei.value.code == -3
+            with pytest.raises(fhe_amd.FheHipError) as ei:
+                g.rotate_mixed(gal, dev(c0), Li, batch=B)
+            assert ei.value.code == -3
+    finally:
+        g.set_tuning(fhe_amd.hip.TUNE_RELIN_KERNEL, 1)
+
+
 def test_config1_roundtrip_decrypted_plaintext_level():
     """BASELINE config 1 (N=2^13, L=K=4): encrypt -> multiply_and_relin on the GPU -> decrypt; ciphertext limbs
     and decrypted plaintext limbs bit-exact vs the oracle, and the plaintext equals a*b/q_last up to noise."""
