@@ -635,11 +635,13 @@ def _uniform(o, idx, rng):
     return np.stack([rng.integers(0, int(o.primes[i]), o.N, dtype=np.uint64) for i in idx])
 
 
-def test_config3_full_size_bit_exact():
+@pytest.mark.parametrize("sp", [True, False])
+def test_config3_full_size_bit_exact(sp):
     """BASELINE config 3 at full size (N=2^16, Li=L=30): one multiply + relinearize + rescale, every output limb equal to the
-    CPU oracle's.  Keys are uniform polynomials (computationally what real keys are): the arithmetic does not care."""
+    CPU oracle's, on the repository's prime table and on generic 62-bit primes (the kernels a caller's own table runs).
+    Keys are uniform polynomials (computationally what real keys are): the arithmetic does not care."""
     logN, L, K, Li = 16, 30, 1, 30
-    o, g = ctx_pair(logN, L, K)
+    o, g = ctx_pair(logN, L, K, sp)
     rng = np.random.default_rng(33)
     beta = np.stack([_uniform(o, range(L), rng) for _ in range(L)])
     alpha = np.stack([_uniform(o, range(L), rng) for _ in range(L)])
@@ -654,13 +656,16 @@ def test_config3_full_size_bit_exact():
     assert np.array_equal(h[0, 0], wb) and np.array_equal(h[0, 1], wa)
     assert np.array_equal(h[1], h[0])
     del beta, alpha
-    g.close(); _ctx_cache.pop((logN, L, K, True), None)
+    g.close(); _ctx_cache.pop((logN, L, K, sp), None)
 
 
-def test_config4_full_size_bit_exact():
-    """BASELINE config 4 at full size (N=2^16, Li=L=K=30): one rotation key switch equal to the CPU oracle's, limb for limb."""
+@pytest.mark.parametrize("sp", [True, False])
+def test_config4_full_size_bit_exact(sp):
+    """BASELINE config 4 at full size (N=2^16, Li=L=K=30): one rotation key switch equal to the CPU oracle's, limb for limb, on both
+    prime families; once as the library picks its base-conversion kernels for a batch of two, once with both conversions on the
+    matrix cores (what the batch-64 bench shape runs)."""
     logN, L, K, Li = 16, 30, 30, 30
-    o, g = ctx_pair(logN, L, K)
+    o, g = ctx_pair(logN, L, K, sp)
     rng = np.random.default_rng(44)
     gal = o.rotation_galois(1)
     rkb, rka = _uniform(o, range(L + K), rng), _uniform(o, range(L + K), rng)
@@ -671,7 +676,12 @@ def test_config4_full_size_bit_exact():
     g.rotate(gal, d, Li, batch=2)
     h = host(d)
     assert np.array_equal(h[0, 0], wb) and np.array_equal(h[0, 1], wa) and np.array_equal(h[1], h[0])
-    g.close(); _ctx_cache.pop((logN, L, K, True), None)
+    g.set_tuning(fhe_amd.hip.TUNE_BCONV, 2)
+    d = dev(np.stack([ct, ct]))
+    g.rotate(gal, d, Li, batch=2)
+    h = host(d)
+    assert np.array_equal(h[0, 0], wb) and np.array_equal(h[0, 1], wa) and np.array_equal(h[1], h[0])
+    g.close(); _ctx_cache.pop((logN, L, K, sp), None)
 
 
 @pytest.mark.parametrize("logN,L,K,Li,B", [(13, 6, 2, 5, 3), (14, 4, 4, 2, 2), (15, 3, 1, 3, 1), (13, 9, 3, 9, 2), (15, 16, 2, 16, 2)])  # last: BASELINE config 5 shape
