@@ -25,7 +25,7 @@
 // 2^22 + (a byte of D), so every S is a non-negative 24-bit number, where D = -2^22 (2^64 - 1)/255 mod p is chosen per target so
 // that the whole offset is a multiple of the target prime and never has to be taken out again.  U + offset (< 2^81) is put
 // together with 32-bit shift-adds, one funnel shift and one carry chain (10 instructions) and taken through ONE 64-bit Montgomery
-// reduction: ~25 VALU instructions and 8 NS / 4 MFMAs per (coefficient, target) instead of ~250 VALU instructions.
+// reduction: ~25 VALU instructions per (coefficient, target) and 2 NS MFMAs per 16 coefficients x 4 targets instead of ~250 VALU instructions.
 // MFMA and VALU work of one SIMD overlap only in part (tools/ubench/mfma_valu.hip: a wave of MFMAs leaves the vector ALU ~40 % of
 // its issue slots), so both counts matter.
 //
